@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native pruned RNN-T loss.
+
+One "step" = one pass of the whole hot path over one batch of synthetic utterances (BASELINE.json
+config "rnnt_loss_pruned s_range=5 B=32 T=1000 S=200 C=500", SURVEY.md 8d "c3"), inputs resident in HBM:
+
+  rnnt_loss_simple(calc_gradients=True)          px/py builder + recursion forward + backward (occupancies)
+  get_rnnt_prune_ranges(s_range=5)               prune ranges (int32)
+  do_rnnt_pruning                                prune gather -> am_pruned, lm_pruned [B,T,5,C]
+  logits = sigmoid(am_pruned + lm_pruned)        joiner stand-in of the reference's own test
+                                                 (tf_fast_rnnt/python/tests/simple_rnnt_loss_test.py:345-348)
+  rnnt_loss_pruned                               logsumexp + band->lattice + recursion forward + backward
+  (0.5 * simple + pruned).backward()             d/d logits (native), then torch autograd back to am, lm
+
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank processes its own batch of
+B utterances (the batch dimension shards with no data-path collective; weak scaling) and the scalar loss
+is all-reduced once per step over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "tf-fast-rnnt_amd"),):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+CONFIGS = {
+    # name: (B, T, S, C, s_range)
+    "c2": (32, 512, 100, 500, 5),
+    "c3": (32, 1000, 200, 500, 5),
+    "c4": (32, 2000, 300, 1024, 5),     # per-GPU share of B=256 over 8 GPUs
+    "c5": (8, 8000, 1000, 512, 10),
+}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_inputs(B, T, S, C, seed, device, ragged=False):
+    """SURVEY.md 8d synthetic inputs: am, lm ~ N(0,1), symbols ~ U{0..C-2}, blank = C-1, full boundary."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    am = torch.randn((B, T, C), generator=g, dtype=torch.float32).to(device)
+    lm = torch.randn((B, S + 1, C), generator=g, dtype=torch.float32).to(device)
+    symbols = torch.randint(0, C - 1, (B, S), generator=g, dtype=torch.int32).to(device)
+    boundary = torch.zeros((B, 4), dtype=torch.int32)
+    boundary[:, 2] = S
+    boundary[:, 3] = T
+    if ragged:
+        t_end = torch.randint((T + 1) // 2, T + 1, (B,), generator=g)
+        t_end[0] = T
+        s_end = torch.minimum(torch.randint((S + 1) // 2, S + 1, (B,), generator=g), t_end)
+        s_end[0] = S
+        boundary[:, 2] = s_end.to(torch.int32)
+        boundary[:, 3] = t_end.to(torch.int32)
+    return dict(am=am, lm=lm, symbols=symbols, boundary=boundary.to(device), blank=C - 1, B=B, T=T, S=S, C=C)
+
+
+def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5):
+    """One full step of the hot path (see module docstring).  Returns the scalar loss (and internals)."""
+    import tf_fast_rnnt as ft
+    am = inp["am"].detach().requires_grad_(True)
+    lm = inp["lm"].detach().requires_grad_(True)
+    sym, bd, blank = inp["symbols"], inp["boundary"], inp["blank"]
+    simple_loss, (px_grad, py_grad) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank,
+                                                         boundary=bd, reduction="sum", calc_gradients=True)
+    ranges = ft.get_rnnt_prune_ranges(px_grad=px_grad, py_grad=py_grad, boundary=bd, s_range=s_range)
+    am_p, lm_p = ft.do_rnnt_pruning(am=am, lm=lm, ranges=ranges)
+    logits = torch.sigmoid(am_p + lm_p)
+    if keep:
+        logits.retain_grad()
+    pruned_loss = ft.rnnt_loss_pruned(logits=logits, symbols=sym, ranges=ranges, termination_symbol=blank,
+                                      boundary=bd, reduction="sum")
+    loss = simple_loss_scale * simple_loss + pruned_loss
+    loss.backward()
+    if keep:
+        return dict(loss=loss.detach(), simple_loss=simple_loss.detach(), pruned_loss=pruned_loss.detach(),
+                    ranges=ranges, px_grad=px_grad, py_grad=py_grad, logits_grad=logits.grad,
+                    am_grad=am.grad, lm_grad=lm.grad)
+    return loss.detach()
+
+
+# ------------------------------------------------------------------------------------------------ profiling
+class CallTimer:
+    """Brackets every native C-ABI call with two HIP events recorded on the stream the kernels are
+    launched on (torch's current stream: the package passes exactly that stream to the C ABI)."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        if not self.enabled:
+            yield
+            return
+        st = torch.cuda.current_stream()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        try:
+            yield
+        finally:
+            e1.record(st)
+            self.records.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = dict(calls=len(ms), avg_us=1e3 * float(np.mean(ms)), total_ms=float(np.sum(ms)))
+        return out
+
+
+def algorithmic_bytes(B, T, S, C, r):
+    """SURVEY.md 8(d) algorithmic bytes per native call (f32 = 4 B).  L = lattice cells."""
+    L = B * (S + 1) * (T + 1)
+    npx, npy = B * S * (T + 1), B * (S + 1) * T
+    N = 4 * B * T * r * C
+    return {
+        # fwd reads px,py and writes p; bwd (reference algorithm) reads px,py,p and writes both grads: 32 L total
+        "ftr_mutual_information_fwd_f32": 4 * (npx + npy + L),
+        "ftr_mutual_information_bwd_f32": 4 * (npx + npy + L + npx + npy),
+        "ftr_prune_ranges_i32": 4 * (npx + npy + B * T * r),
+        "ftr_do_pruning_f32": 4 * (B * T * C + B * (S + 1) * C + B * T * r) + 2 * N,
+        "ftr_pruned_logprobs_fwd_f32": N + 4 * (npx + npy),              # stream logits once, write px,py
+        "ftr_pruned_logprobs_bwd_f32": 2 * N + 4 * (npx + npy),          # re-read logits, write the gradient
+    }
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(B, T, S, C, r, sample_B=16, seed=0):
+    """The oracle (CPU port of the same path) timed on this host, 1 thread, on `sample_B` utterances of the
+    same workload: px/py builder + recursion fwd+bwd + ranges + gather + sigmoid + pruned log-probs +
+    recursion fwd+bwd + gradient w.r.t. logits."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rnnt_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = contextlib.nullcontext()
+    O.build()
+    rng = np.random.default_rng(seed)
+    am = rng.standard_normal((sample_B, T, C)).astype(np.float32)
+    lm = rng.standard_normal((sample_B, S + 1, C)).astype(np.float32)
+    sym = rng.integers(0, C - 1, (sample_B, S)).astype(np.int32)
+    bd = np.zeros((sample_B, 4), np.int32); bd[:, 2] = S; bd[:, 3] = T
+    os.environ["OMP_NUM_THREADS"] = "1"
+    with limiter:
+        t0 = time.perf_counter()
+        _, (gx, gy) = O.rnnt_loss_simple(lm, am, sym, C - 1, bd, reduction="sum", calc_gradients=True)
+        ranges = O.get_rnnt_prune_ranges(gx, gy, bd, r)
+        am_p, lm_p = O.do_rnnt_pruning(am, lm, ranges)
+        logits = (1.0 / (1.0 + np.exp(-(am_p + lm_p)))).astype(np.float32)
+        O.rnnt_loss_pruned_grad(logits, sym, ranges, C - 1, bd, reduction="sum")
+        dt = time.perf_counter() - t0
+    return dict(value=sample_B / dt, unit="utterances/s", cores=1, kind="port",
+                sample=f"{sample_B} of {B} utterances of the same workload (oracle/ C + numpy, single thread, "
+                       f"{dt:.1f} s of CPU work; loss pipeline without the torch-autograd tail to am/lm)")
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ragged", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import tf_fast_rnnt as ft
+    B, T, S, C, r = CONFIGS[args.config]
+    inp = make_inputs(B, T, S, C, seed=1000 + rank, device=dev, ragged=args.ragged)
+
+    def step():
+        loss = pruned_step(inp, r)
+        if dist is not None:
+            dist.all_reduce(loss)           # the single scalar exchange of the sharded loss
+        return loss
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer = CallTimer()
+    ft._lib.set_profile_hook(timer)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    timer.enabled = (rank == 0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    ft._lib.set_profile_hook(None)
+    peak_mb = torch.cuda.max_memory_allocated(dev) / 2**20
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+    calls = timer.summary()
+    alg = algorithmic_bytes(B, T, S, C, r)
+    kernels = {}
+    for name, rec in calls.items():
+        per_step_calls = rec["calls"] / args.steps
+        kernels[name] = dict(avg_us=round(rec["avg_us"], 2), calls_per_step=per_step_calls,
+                             algorithmic_MB=round(alg[name] / 1e6, 1) if name in alg else None,
+                             GBps=round(alg[name] / (rec["avg_us"] * 1e-6) / 1e9, 1) if name in alg else None)
+    # dominant native call of the step = largest total time
+    dom = max(calls, key=lambda n: calls[n]["total_ms"]) if calls else None
+    roofline = None
+    if dom is not None and dom in alg:
+        achieved = alg[dom] / (calls[dom]["avg_us"] * 1e-6) / 1e9
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        avg_launch_us=round(calls[dom]["avg_us"], 2), algorithmic_bytes=alg[dom])
+    native_us = sum(rec["total_ms"] for rec in calls.values()) * 1e3 / args.steps
+    out = {
+        "metric": "rnnt_loss_pruned_fwd_bwd_throughput",
+        "value": round(value, 2),
+        "unit": "utterances/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "us_per_step": round(1e3 * ms_per_step, 1),
+        "peak_mem_mb": round(peak_mb, 1),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: rnnt_loss_pruned fwd+bwd step, B={B}/GPU T={T} S={S} C={C} s_range={r}, "
+                               f"regular, {'ragged' if args.ragged else 'full'} boundary",
+                   "global_batch": world * B, "sharding": f"batch x{world}, one scalar all-reduce/step"},
+        "roofline": roofline,
+        "native_us_per_step": round(native_us, 1),
+        "kernels": kernels,
+        "loss": float(last.item()),
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(B, T, S, C, r)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * include/ftr.h -- C ABI of the MI355X-native pruned RNN-T loss hot path ("ftr" = fast transducer).
+ *
+ * This is the drop-in boundary for the native layer of Samsung/tf-fast-rnnt: every entry point
+ * replaces one host launcher / op kernel of the reference (cited per function, paths relative to
+ * /root/reference).  Conventions, fixed for every function:
+ *
+ *   - plain C types only: device pointers (hipMalloc'd, or anything HIP can dereference on the
+ *     current device), int sizes, an opaque `void* stream` (a hipStream_t; NULL = default stream);
+ *   - dense row-major tensors, last axis contiguous, float32 / int32 exactly as the reference's op
+ *     registration (tf_fast_rnnt/python/csrc/tf_fast_rnnt_op.cc:27-38);
+ *   - asynchronous on `stream`, no host synchronisation, no allocation inside (graph-capturable);
+ *     scratch is passed in by the caller (the reference allocates it with allocate_temp,
+ *     tf_fast_rnnt_op.cc:66-67,90-91);
+ *   - return value: 1 on success -- the reference's launchers return 1 (mutual_information_cuda.cu:810,
+ *     873,1011) and its op maps anything else to tf::errors::Internal (tf_fast_rnnt_op.cc:114-116);
+ *     <= 0 is an FTR_ERR_* code and ftr_last_error() describes it.  There is no CPU fallback: with no
+ *     usable HIP device the functions return FTR_ERR_NO_DEVICE.
+ */
+#ifndef FTR_H_
+#define FTR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTR_OK 1
+#define FTR_ERR_INVALID_ARG 0
+#define FTR_ERR_UNSUPPORTED (-1)
+#define FTR_ERR_LAUNCH (-2)
+#define FTR_ERR_NO_DEVICE (-3)
+
+/* ABI version (major*100 + minor) and the package version string the Python layer re-exports
+ * (__version__ == "1.2", tf_fast_rnnt/python/tf_fast_rnnt/__init__.py:36). */
+int ftr_abi_version(void);
+const char* ftr_package_version(void);
+/* Thread-local description of the last non-success return on this thread ("" if none). */
+const char* ftr_last_error(void);
+/* Selects the mutual-information kernel family: 0 = "wavefront" (default, skewed wave64 DP with LDS
+ * staged tiles), 1 = "plain" (one thread per lattice row, reference arithmetic; diagnostic).  Also
+ * settable with the environment variable FTR_MI_IMPL=wavefront|plain.  Returns the previous value. */
+int ftr_set_mi_impl(int impl);
+int ftr_get_mi_impl(void);
+
+/* Number of floats of fwd->bwd workspace (`p` below) for a problem size: B*(S+1)*(T+1), the shape
+ * of the reference's temp `p` (tf_fast_rnnt_op.cc:65-67).  Its CONTENT is implementation defined
+ * (see DESIGN.md): the same buffer must be handed unchanged from _fwd to _bwd. */
+size_t ftr_mutual_information_workspace_floats(int B, int S, int T);
+
+/*
+ * Forward recursion.  Replaces MutualInformationCuda<float>
+ * (tf_fast_rnnt/csrc/mutual_information.h:134-141, mutual_information_cuda.cu:765-811).
+ *   px [B,S,T+1] (modified==0) or [B,S,T] (modified!=0); py [B,S+1,T];
+ *   boundary [B,4] = (s_begin,t_begin,s_end,t_end) or NULL => (0,0,S,T);
+ *   p   workspace, ftr_mutual_information_workspace_floats() floats, written;
+ *   ans [B] = p[b,s_end,t_end] of the recursion documented at mutual_information.h:101-126.
+ */
+int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary,
+                                   float* p, float* ans, int B, int S, int T, int modified,
+                                   void* stream);
+
+/*
+ * Backward recursion.  Replaces MutualInformationBackwardCuda<float>
+ * (mutual_information.h:151-162, mutual_information_cuda.cu:817-874) together with the two memsets
+ * of the op (tf_fast_rnnt_op.cc:93-96): px_grad (shape of px) and py_grad (shape of py) are FULLY
+ * written, zeros outside the boundary rectangle.
+ *   p        the workspace written by ftr_mutual_information_fwd_f32 on the same inputs;
+ *   p_grad   optional scratch [B,S+1,T+1]; only the "plain" family uses it (may be NULL for
+ *            "wavefront", which keeps p_grad on chip);
+ *   ans_grad [B], read; if overwrite_ans_grad it is overwritten with p_grad[b,s_begin,t_begin],
+ *            which equals the seed when everything is consistent (mutual_information_cuda.cu:510-514).
+ */
+int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32_t* boundary,
+                                   const float* p, float* p_grad, float* px_grad, float* py_grad,
+                                   float* ans_grad, int overwrite_ans_grad, int B, int S, int T,
+                                   int modified, void* stream);
+
+/* Inclusive prefix-min along rows of an int32 [rows, cols] matrix.  Replaces CumminCuda<int32_t>
+ * (mutual_information.h:164-168, mutual_information_cuda.cu:895-1012; op "Cummin",
+ * tf_fast_rnnt_op.cc:36-38,135-165). */
+int ftr_cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, void* stream);
+
+/*
+ * Prune ranges.  Replaces get_rnnt_prune_ranges + _adjust_pruning_lower_bound +
+ * _monotonic_lower_bound (tf_fast_rnnt/python/tf_fast_rnnt/rnnt_loss.py:553-761), i.e. ~15 TF ops
+ * and two Cummin launches, by two kernels.
+ *   px_grad [B,S,T1] (T1 = T+1 regular, T modified), py_grad [B,S+1,T], boundary [B,4] (required);
+ *   s_range as given by the caller; r_eff = (s_range > S ? S+1 : s_range) (rnnt_loss.py:710-711);
+ *   ranges  [B,T,r_eff] int32, written; s_begin_scratch [B,T] int32 scratch.
+ * Canonical arithmetic (bit-exact with oracle/): cumsum along S sequential in f32, window sum
+ * cumsum[s0+r]-cumsum[s0], minus px_grad[s0-1] (0 for s0==0), first maximum wins.
+ * Returns FTR_OK; r_eff is returned through *r_eff_out when non-NULL.
+ */
+int ftr_prune_ranges_i32(const float* px_grad, const float* py_grad, const int32_t* boundary,
+                         int32_t* ranges, int32_t* s_begin_scratch, int B, int S, int T, int T1,
+                         int s_range, int* r_eff_out, void* stream);
+
+/* Prune gather.  Replaces do_rnnt_pruning (rnnt_loss.py:763-812):
+ * am_pruned[b,t,k,:] = am[b,t,:], lm_pruned[b,t,k,:] = lm[b,ranges[b,t,k],:].
+ * am [B,T,C], lm [B,S1,C], ranges [B,T,r]; outputs [B,T,r,C]. */
+int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, float* am_pruned,
+                       float* lm_pruned, int B, int T, int S1, int C, int r, void* stream);
+
+/*
+ * Pruned log-probs, forward.  Replaces get_rnnt_logprobs_pruned for rnnt_type "regular"
+ * (modified==0) / "modified" (modified!=0) (rnnt_loss.py:853-1020: logsumexp, two gathers, pad,
+ * _roll_by_shifts, transpose, fix_for_boundary) and, when delay_penalty > 0, the penalty block
+ * (rnnt_loss.py:1097-1114).
+ *   logits [B,T,r,C]; symbols [B,S]; ranges [B,T,r]; boundary [B,4] or NULL;
+ *   lse [B,T,r] written (kept for the backward);
+ *   px [B,S,T1], py [B,S+1,T] written in full: band values, -inf elsewhere, px[:,:,T] = -inf and
+ *   px[b,:,t_end[b]] = -inf for regular.
+ */
+int ftr_pruned_logprobs_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                const int32_t* boundary, int termination_symbol, double delay_penalty,
+                                float* lse, float* px, float* py, int B, int T, int S, int C, int r,
+                                int modified, void* stream);
+
+/*
+ * Pruned log-probs, backward: d loss / d logits given d loss / d px and d loss / d py lattices
+ * (what TF autodiff replays for rnnt_loss.py:942-1016).  With scale != NULL the lattice gradients
+ * are multiplied by scale[b] on the fly (fuses _RNNTLossGrad, __init__.py:154-162).
+ *   glogits [B,T,r,C] fully written.
+ */
+int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                const int32_t* boundary, int termination_symbol, const float* lse,
+                                const float* gpx, const float* gpy, const float* scale,
+                                float* glogits, int B, int T, int S, int C, int r, int modified,
+                                void* stream);
+
+/* Hardware self-test used by smoke()/tests: checks on the device that the primitives the wavefront
+ * kernels rely on behave as assumed (full-wave DPP shift wave_shr:1 with lane 0 keeping its old value;
+ * 16-byte global loads/stores at 4-byte alignment).  scratch_dev: >= 8 KiB of device memory; after the
+ * stream has drained, ((int*)scratch_dev)[0] == 1 means pass. */
+int ftr_selftest(void* scratch_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTR_H_ */

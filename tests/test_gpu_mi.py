@@ -1,0 +1,175 @@
+"""Parity of the native mutual-information ops against the oracle, through the C ABI (via the ctypes
+binding the package uses).  Tolerances (north_star: "loss and px/py gradients within 1e-4 relative"):
+
+* ans / loss: elementwise rtol 1e-4 against the float32 oracle (observed ~1e-6).
+* px_grad / py_grad: normwise relative error (max|diff| / max|ref|) <= 1e-4 against the float32 oracle
+  on lattices where float32 log-domain arithmetic itself is accurate to that level, and against the
+  float64 oracle everywhere.  On long lattices (|p| of several thousand) the reference arithmetic is
+  itself only ~1e-3 accurate (float32 oracle vs float64 oracle: 7e-4 normwise at T=1000,S=200,C=500,
+  measured in DESIGN.md), so there the bound versus the float32 oracle is the oracle's own error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_rel, random_lattice
+
+pytestmark = pytest.mark.gpu
+
+IMPLS = {"wavefront": 0, "plain": 1}
+
+
+def _run(ft, dev, px, py, bd, impl, need_grads=True):
+    from tf_fast_rnnt.mutual_information import mi_forward_backward
+    L = ft._lib.lib()
+    prev = L.ftr_set_mi_impl(IMPLS[impl])
+    try:
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        ans, gx, gy, chk = mi_forward_backward(t(px), t(py), t(bd), need_grads, return_ans_grad_check=True)
+        torch.cuda.synchronize()
+        out = [ans.cpu().numpy()] + [None if g is None else g.cpu().numpy() for g in (gx, gy, chk)]
+    finally:
+        L.ftr_set_mi_impl(prev)
+    return out
+
+
+def test_selftest(ft, dev):
+    scratch = torch.zeros(4096, dtype=torch.int32, device=dev)
+    ft._lib.check(ft._lib.lib().ftr_selftest(scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    assert int(scratch[0].item()) == 1
+
+
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("modified", [False, True])
+@pytest.mark.parametrize("shape", [(2, 4, 8), (3, 1, 1), (3, 7, 10), (4, 50, 200), (2, 63, 70), (2, 64, 65),
+                                   (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40)])
+def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
+    B, S, T = shape
+    px, py, bd = random_lattice(100 + S + T, B, S, T, modified=modified, ragged=True)
+    ans, gx, gy, chk = _run(ft, dev, px, py, bd, impl)
+    o_ans, o_p = oracle.mi_forward(px, py, bd)
+    o_gx, o_gy, o_chk = oracle.mi_backward(px, py, bd, o_p)
+    np.testing.assert_allclose(ans, o_ans, rtol=1e-4, atol=1e-5)
+    assert max_rel(gx, o_gx) <= 1e-4 and max_rel(gy, o_gy) <= 1e-4, (max_rel(gx, o_gx), max_rel(gy, o_gy))
+    # the reference's self-check (mutual_information_cuda.cu:510-514): recomputed ans_grad == seed
+    nonempty = (bd[:, 2] >= bd[:, 0]) & (bd[:, 3] >= bd[:, 1])
+    np.testing.assert_allclose(chk[nonempty], 1.0, rtol=2e-4)
+    # zeros outside the boundary rectangle, exactly
+    for b in range(B):
+        se, te = bd[b, 2], bd[b, 3]
+        assert not gx[b, se:, :].any() and not gy[b, se + 1:, :].any()
+        assert not gx[b, :, te + 1:].any() and not gy[b, :, te:].any()
+
+
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("modified", [False, True])
+def test_mi_begin_offsets_and_empty(ft, dev, oracle, impl, modified):
+    B, S, T = 5, 20, 37
+    px, py, bd = random_lattice(5, B, S, T, modified=modified, ragged=True, begin_offsets=True)
+    bd[1] = [3, 5, 3, 5]          # single cell: ans = 0
+    bd[2] = [0, 0, 0, T]          # no symbols at all
+    ans, gx, gy, chk = _run(ft, dev, px, py, bd, impl)
+    o_ans, o_p = oracle.mi_forward(px, py, bd)
+    o_gx, o_gy, _ = oracle.mi_backward(px, py, bd, o_p)
+    np.testing.assert_allclose(ans, o_ans, rtol=1e-4, atol=1e-5)
+    assert ans[1] == 0.0
+    assert max_rel(gx, o_gx) <= 1e-4 and max_rel(gy, o_gy) <= 1e-4
+
+
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("modified", [False, True])
+@pytest.mark.parametrize("frac", [0.02, 0.3])
+def test_mi_neg_inf_entries(ft, dev, oracle, impl, modified, frac):
+    """-inf inside px/py (the pruned lattices are >97% -inf): same finite/-inf pattern of ans, no NaN."""
+    B, S, T = 6, 30, 45
+    px, py, bd = random_lattice(11, B, S, T, modified=modified, neg_inf_frac=frac, ragged=False)
+    ans, gx, gy, _ = _run(ft, dev, px, py, bd, impl)
+    o_ans, o_p = oracle.mi_forward(px, py, bd)
+    o_gx, o_gy, _ = oracle.mi_backward(px, py, bd, o_p)
+    assert np.array_equal(np.isfinite(ans), np.isfinite(o_ans))
+    fin = np.isfinite(o_ans)
+    np.testing.assert_allclose(ans[fin], o_ans[fin], rtol=1e-4, atol=1e-5)
+    assert not np.isnan(gx).any() and not np.isnan(gy).any()
+    if fin.any():   # utterances with no surviving path have reference-defined garbage gradients
+        assert max_rel(gx[fin], o_gx[fin]) <= 1e-4 and max_rel(gy[fin], o_gy[fin]) <= 1e-4
+
+
+def test_mi_boundary_none(ft, dev, oracle):
+    px, py, _ = random_lattice(3, 2, 9, 14, ragged=False)
+    ans, gx, gy, _ = _run(ft, dev, px, py, None, "wavefront")
+    o_ans, o_p = oracle.mi_forward(px, py, None)
+    o_gx, o_gy, _ = oracle.mi_backward(px, py, None, o_p)
+    np.testing.assert_allclose(ans, o_ans, rtol=1e-4)
+    assert max_rel(gx, o_gx) <= 1e-4 and max_rel(gy, o_gy) <= 1e-4
+
+
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+def test_mi_vs_float64_oracle_long(ft, dev, oracle, impl):
+    """Long lattice with realistic magnitudes (px,py ~ log(1/C)): compare with the float64 oracle and
+    require the native result to be no worse than the float32 reference arithmetic."""
+    B, S, T = 2, 150, 700
+    rng = np.random.default_rng(0)
+    px = (rng.standard_normal((B, S, T + 1)) - 6.0).astype(np.float32)
+    py = (rng.standard_normal((B, S + 1, T)) - 6.0).astype(np.float32)
+    bd = np.array([[0, 0, S, T], [0, 0, S - 11, T - 50]], dtype=np.int32)
+    ans, gx, gy, _ = _run(ft, dev, px, py, bd, impl)
+    a64, p64 = oracle.mi_forward(px, py, bd, dtype=np.float64)
+    gx64, gy64, _ = oracle.mi_backward(px, py, bd, p64, dtype=np.float64)
+    a32, p32 = oracle.mi_forward(px, py, bd)
+    gx32, gy32, _ = oracle.mi_backward(px, py, bd, p32)
+    np.testing.assert_allclose(ans, a64, rtol=1e-4)
+    ref_err = max(max_rel(gx32, gx64), max_rel(gy32, gy64))
+    err = max(max_rel(gx, gx64), max_rel(gy, gy64))
+    assert err <= max(1e-4, 1.5 * ref_err), (err, ref_err)
+
+
+def test_mi_autograd(ft, dev, oracle):
+    """The registered gradient (__init__.py:154-162): d(sum_b w_b ans_b)/d px = w_b * px_grad."""
+    px, py, bd = random_lattice(21, 3, 6, 9, ragged=True)
+    tpx = torch.from_numpy(px).to(dev).requires_grad_(True)
+    tpy = torch.from_numpy(py).to(dev).requires_grad_(True)
+    w = torch.tensor([0.5, -2.0, 3.0], device=dev)
+    ans = ft.mutual_information_recursion(tpx, tpy, torch.from_numpy(bd).to(dev))
+    (ans * w).sum().backward()
+    o_ans, o_p = oracle.mi_forward(px, py, bd)
+    o_gx, o_gy, _ = oracle.mi_backward(px, py, bd, o_p)
+    wn = w.cpu().numpy().reshape(-1, 1, 1)
+    assert max_rel(tpx.grad.cpu().numpy(), wn * o_gx) <= 1e-4
+    assert max_rel(tpy.grad.cpu().numpy(), wn * o_gy) <= 1e-4
+
+
+def test_mi_full_size_properties(ft, dev):
+    """BASELINE config c3 lattice size (B=32,T=1000,S=200): size-independent properties of the occupancies
+    (SURVEY.md section 7.1): sum_s py_grad[:,t] = 1 for t < t_end, sum_t px_grad[s,:] = 1 for s < s_end,
+    recomputed ans_grad = 1, and agreement of the two kernel families."""
+    B, S, T = 32, 200, 1000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    px = (torch.randn((B, S, T + 1), generator=g) - 6.0)
+    py = (torch.randn((B, S + 1, T), generator=g) - 6.0)
+    bd = torch.zeros((B, 4), dtype=torch.int32)
+    bd[:, 2] = S; bd[:, 3] = T
+    bd[1, 2] = 77; bd[1, 3] = 513; bd[2, 2] = 199; bd[2, 3] = 999
+    px = px.scatter(2, bd[:, 3].long().reshape(B, 1, 1).expand(B, S, 1), float("-inf"))
+    outs = {}
+    for impl in ("wavefront", "plain"):
+        outs[impl] = _run(ft, dev, px.numpy(), py.numpy(), bd.numpy(), impl)
+    for impl, (ans, gx, gy, chk) in outs.items():
+        tol = 2e-3 if impl == "plain" else 1e-4     # plain = reference arithmetic: normalisation drifts
+        for b in range(B):
+            se, te = int(bd[b, 2]), int(bd[b, 3])
+            np.testing.assert_allclose(gy[b, :se + 1, :te].sum(axis=0), 1.0, rtol=tol)
+            np.testing.assert_allclose(gx[b, :se, :te + 1].sum(axis=1), 1.0, rtol=tol)
+        np.testing.assert_allclose(chk, 1.0, rtol=tol)
+    np.testing.assert_allclose(outs["wavefront"][0], outs["plain"][0], rtol=1e-5)
+    assert max_rel(outs["wavefront"][1], outs["plain"][1]) <= 5e-3
+    assert max_rel(outs["wavefront"][2], outs["plain"][2]) <= 5e-3
+
+
+def test_cummin(ft, dev, oracle):
+    rng = np.random.default_rng(0)
+    for rows, cols in [(1, 1), (3, 6), (5, 64), (7, 65), (32, 1000), (2, 4097)]:
+        x = rng.integers(-1000, 1000, (rows, cols)).astype(np.int32)
+        out = ft.cummin(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert np.array_equal(out, oracle.cummin(x))
+        assert np.array_equal(out, np.minimum.accumulate(x, axis=1))

@@ -1,0 +1,194 @@
+"""GPU parity of the pruning pipeline and of the loss drivers against the oracle, through the package
+(ctypes -> C ABI -> HIP).  Integer outputs are compared bit-exactly; floats as in test_gpu_mi.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_rel, reference_test_recipe, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _occupancies(oracle, d, **kw):
+    loss, (gx, gy) = oracle.rnnt_loss_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"],
+                                               lm_only_scale=0.1, am_only_scale=0.2, boundary=d["boundary"],
+                                               reduction="none", delay_penalty=0.2, calc_gradients=True, **kw)
+    return loss, gx, gy
+
+
+@pytest.mark.parametrize("cfg", [(1234, 2, 10, 7, 4), (12345, 2, 200, 50, 50), (7, 5, 90, 33, 20)])
+def test_prune_ranges_bit_exact(ft, dev, oracle, cfg):
+    """simple_rnnt_loss_test.py:291-336 scenario: occupancies from the smoothed loss, r = 2..S+3."""
+    d = reference_test_recipe(*cfg)
+    _, gx, gy = _occupancies(oracle, d)
+    S = d["S"]
+    for r in list(range(2, min(S + 4, 12))) + [S, S + 1, S + 3]:
+        got = ft.get_rnnt_prune_ranges(_t(gx, dev), _t(gy, dev), _t(d["boundary"], dev), r).cpu().numpy()
+        want = oracle.get_rnnt_prune_ranges(gx, gy, d["boundary"], r)
+        assert got.dtype == np.int32 and got.shape == want.shape
+        assert np.array_equal(got, want), f"r={r}"
+        # documented properties (rnnt_loss.py:673-677)
+        s0 = got[:, :, 0]
+        assert (np.diff(s0, axis=1) >= 0).all() and (s0 >= 0).all()
+        assert (np.diff(s0, axis=1) <= max(got.shape[2] - 1, 0)).all()
+
+
+def test_prune_ranges_modified_and_ties(ft, dev, oracle):
+    rng = np.random.default_rng(3)
+    B, S, T = 3, 9, 17
+    gy = rng.random((B, S + 1, T)).astype(np.float32)
+    gx = rng.random((B, S, T)).astype(np.float32)          # modified: T1 == T
+    gy[0] = 0.25                                            # exact ties everywhere -> first maximum
+    gx[0] = 0.25
+    bd = np.array([[0, 0, S, T], [0, 0, 4, 9], [0, 0, 2, 17]], dtype=np.int32)
+    for r in (1, 2, 3, 5, 20):
+        got = ft.get_rnnt_prune_ranges(_t(gx, dev), _t(gy, dev), _t(bd, dev), r).cpu().numpy()
+        assert np.array_equal(got, oracle.get_rnnt_prune_ranges(gx, gy, bd, r)), r
+        assert np.array_equal(got, oracle.get_rnnt_prune_ranges_numpy(gx, gy, bd, r)), r
+
+
+def test_adjust_lower_bound_opwise(ft, dev, oracle):
+    """_adjust_pruning_lower_bound built from the native cummin op, like the reference (rnnt_loss.py:587-641)."""
+    from tf_fast_rnnt.rnnt_loss import _adjust_pruning_lower_bound, _monotonic_lower_bound
+    x = np.array([[12, 18, 5, 4, 18, 17], [11, 14, 14, 3, 10, 4], [19, 3, 8, 13, 7, 19]], dtype=np.int32)
+    want = np.array([[4, 4, 4, 4, 17, 17], [3, 3, 3, 3, 4, 4], [3, 3, 7, 7, 7, 19]], dtype=np.int32)  # rnnt_loss.py:568-574
+    assert np.array_equal(_monotonic_lower_bound(_t(x, dev)).cpu().numpy(), want)
+    v = np.array([0, 2, 1, 3, 6, 5, 8], dtype=np.int32)                                                  # rnnt_loss.py:561-563
+    assert np.array_equal(_monotonic_lower_bound(_t(v, dev)).cpu().numpy(), [0, 1, 1, 3, 5, 5, 8])
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 30, (4, 50)).astype(np.int32)
+    for r in (2, 3, 7):
+        assert np.array_equal(_adjust_pruning_lower_bound(_t(s, dev), r).cpu().numpy(), oracle.adjust_pruning_lower_bound(s, r))
+
+
+@pytest.mark.parametrize("C", [16, 50, 7])
+def test_do_pruning_bit_exact_and_grad(ft, dev, oracle, C):
+    d = synthetic(1, 3, 21, 9, C, ragged=True)
+    _, gx, gy = _occupancies(oracle, d)
+    ranges = oracle.get_rnnt_prune_ranges(gx, gy, d["boundary"], 4)
+    am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+    am_p, lm_p = ft.do_rnnt_pruning(am, lm, _t(ranges, dev))
+    o_am, o_lm = oracle.do_rnnt_pruning(d["am"], d["lm"], ranges)
+    assert np.array_equal(am_p.detach().cpu().numpy(), o_am) and np.array_equal(lm_p.detach().cpu().numpy(), o_lm)
+    w1 = torch.randn_like(am_p); w2 = torch.randn_like(lm_p)
+    ((am_p * w1).sum() + (lm_p * w2).sum()).backward()
+    np.testing.assert_allclose(am.grad.cpu().numpy(), w1.sum(dim=2).cpu().numpy(), rtol=1e-6)
+    want = np.zeros_like(d["lm"])
+    w2n = w2.cpu().numpy()
+    B, T, r = ranges.shape
+    for b in range(B):
+        for t in range(T):
+            for k in range(r):
+                want[b, ranges[b, t, k]] += w2n[b, t, k]
+    np.testing.assert_allclose(lm.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
+def test_pruned_logprobs_exact_pattern(ft, dev, oracle, rnnt_type):
+    d = reference_test_recipe(1234, 2, 40, 12, 16)
+    _, gx, gy = _occupancies(oracle, d)
+    r = 4
+    ranges = oracle.get_rnnt_prune_ranges(gx, gy, d["boundary"], r)
+    am_p, lm_p = oracle.do_rnnt_pruning(d["am"], d["lm"], ranges)
+    logits = (1.0 / (1.0 + np.exp(-(am_p + lm_p)))).astype(np.float32)
+    px, py = ft.get_rnnt_logprobs_pruned(_t(logits, dev), _t(d["symbols"], dev), _t(ranges, dev), d["termination_symbol"],
+                                         _t(d["boundary"], dev), rnnt_type)
+    o_px, o_py = oracle.get_rnnt_logprobs_pruned(logits, d["symbols"], ranges, d["termination_symbol"], d["boundary"], rnnt_type)
+    px = px.cpu().numpy(); py = py.cpu().numpy()
+    assert px.shape == o_px.shape and py.shape == o_py.shape
+    assert np.array_equal(np.isneginf(px), np.isneginf(o_px)) and np.array_equal(np.isneginf(py), np.isneginf(o_py))
+    fin = np.isfinite(o_px)
+    np.testing.assert_allclose(px[fin], o_px[fin], rtol=1e-5, atol=1e-6)
+    fin = np.isfinite(o_py)
+    np.testing.assert_allclose(py[fin], o_py[fin], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cfg", [(1234, 2, 10, 7, 4), (12345, 2, 200, 50, 50)])
+def test_reference_scenario(ft, dev, oracle, cfg):
+    """The scenario of the reference's only active test (simple_rnnt_loss_test.py:256-369), with
+    assertions instead of prints: unpruned rnnt_loss, smoothed loss with occupancies, then for a sweep of
+    s_range: ranges -> gather -> sigmoid joiner -> pruned loss and its gradient w.r.t. logits."""
+    d = reference_test_recipe(*cfg)
+    am, lm, sym, bd = (_t(d[k], dev) for k in ("am", "lm", "symbols", "boundary"))
+    blank = d["termination_symbol"]
+    # unpruned rnnt_loss on joiner logits
+    logits_np = 1.0 / (1.0 + np.exp(-(d["am"][:, :, None, :] + d["lm"][:, None, :, :])))
+    logits = _t(logits_np.astype(np.float32), dev)
+    loss = ft.rnnt_loss(logits=logits, symbols=sym, termination_symbol=blank, boundary=bd, reduction="mean", delay_penalty=0.2)
+    o_loss = oracle.rnnt_loss(logits_np.astype(np.float32), d["symbols"], blank, d["boundary"], reduction="mean", delay_penalty=0.2)
+    np.testing.assert_allclose(loss.item(), o_loss, rtol=1e-4)
+    # smoothed
+    sl, (pxg, pyg) = ft.rnnt_loss_smoothed(lm=lm, am=am, symbols=sym, termination_symbol=blank, boundary=bd,
+                                           lm_only_scale=0.1, am_only_scale=0.2, reduction="none", delay_penalty=0.2,
+                                           calc_gradients=True)
+    o_sl, o_gx, o_gy = _occupancies(oracle, d)
+    np.testing.assert_allclose(sl.cpu().numpy(), o_sl, rtol=1e-4)
+    assert max_rel(pxg.cpu().numpy(), o_gx) <= 1e-4 and max_rel(pyg.cpu().numpy(), o_gy) <= 1e-4
+    S = d["S"]
+    for r in sorted(set([2, 3, 5, min(8, S), S, S + 1])):
+        ranges = oracle.get_rnnt_prune_ranges(o_gx, o_gy, d["boundary"], r)
+        got_ranges = ft.get_rnnt_prune_ranges(_t(o_gx, dev), _t(o_gy, dev), bd, r)
+        assert np.array_equal(got_ranges.cpu().numpy(), ranges)
+        am_p, lm_p = ft.do_rnnt_pruning(am=am, lm=lm, ranges=got_ranges)
+        lg = torch.sigmoid(am_p + lm_p).detach().requires_grad_(True)
+        for reduction in ("mean", "sum"):
+            lg.grad = None
+            pl = ft.rnnt_loss_pruned(logits=lg, symbols=sym, ranges=got_ranges, termination_symbol=blank, boundary=bd,
+                                     reduction=reduction, delay_penalty=0.2, calc_gradients=True)
+            pl.backward()
+            o_pl, o_g = oracle.rnnt_loss_pruned_grad(lg.detach().cpu().numpy(), d["symbols"], ranges, blank, d["boundary"],
+                                                     delay_penalty=0.2, reduction=reduction)
+            np.testing.assert_allclose(pl.item(), o_pl, rtol=1e-4)
+            assert max_rel(lg.grad.cpu().numpy(), o_g) <= 1e-4, (r, reduction, max_rel(lg.grad.cpu().numpy(), o_g))
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
+def test_simple_loss_types_and_grads(ft, dev, oracle, rnnt_type):
+    d = synthetic(5, 3, 24, 8, 12, ragged=True)
+    am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+    loss, (pxg, pyg) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=_t(d["symbols"], dev), termination_symbol=d["termination_symbol"],
+                                           boundary=_t(d["boundary"], dev), rnnt_type=rnnt_type, reduction="none",
+                                           delay_penalty=0.1, calc_gradients=True)
+    o_loss, (o_gx, o_gy) = oracle.rnnt_loss_simple(d["lm"], d["am"], d["symbols"], d["termination_symbol"], d["boundary"],
+                                                   rnnt_type, 0.1, "none", True)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), o_loss, rtol=1e-4)
+    assert pxg.shape == o_gx.shape
+    assert max_rel(pxg.cpu().numpy(), o_gx) <= 1e-4 and max_rel(pyg.cpu().numpy(), o_gy) <= 1e-4
+    loss.sum().backward()       # gradients reach am and lm through the native op
+    assert torch.isfinite(am.grad).all() and torch.isfinite(lm.grad).all()
+    # d loss / d am summed over classes is 0 (the model is normalised over C for every (s,t))
+    np.testing.assert_allclose(am.grad.sum(dim=2).cpu().numpy(), 0.0, atol=2e-4)
+
+
+def test_mean_reduction_and_defaults(ft, dev, oracle):
+    d = synthetic(2, 2, 8, 4, 16)           # BASELINE config c1 shape: B=2 T=8 S=4 C=16
+    out = ft.rnnt_loss_simple(_t(d["lm"], dev), _t(d["am"], dev), _t(d["symbols"], dev), d["termination_symbol"])
+    want = oracle.rnnt_loss_simple(d["lm"], d["am"], d["symbols"], d["termination_symbol"])
+    np.testing.assert_allclose(out.item(), want, rtol=1e-5)
+    with pytest.raises(ValueError):
+        ft.rnnt_loss_simple(_t(d["lm"], dev), _t(d["am"], dev), _t(d["symbols"], dev), d["termination_symbol"], reduction="bogus")
+
+
+def test_full_size_pruned_step_properties(ft, dev):
+    """BASELINE config c3 (B=32,T=1000,S=200,C=500,s_range=5) end to end on the GPU; checks the
+    size-independent properties: ranges monotone / bounded / pinned at the last frame, gather idempotent,
+    pruned loss finite and >= the unpruned-path lower bound property loss_pruned >= simple-lattice bound is
+    not defined, so: gradient rows sum to ~0 (softmax gradient) and occupancies sum to 1 per frame."""
+    from bench import make_inputs, pruned_step
+    inp = make_inputs(B=32, T=1000, S=200, C=500, seed=0, device=dev)
+    out = pruned_step(inp, s_range=5, keep=True)
+    torch.cuda.synchronize()
+    ranges = out["ranges"].cpu().numpy()
+    s0 = ranges[:, :, 0]
+    assert (np.diff(s0, axis=1) >= 0).all() and (np.diff(s0, axis=1) <= 4).all() and (s0 >= 0).all()
+    assert (s0[:, -1] == 200 - 5 + 1).all()
+    assert (ranges == s0[:, :, None] + np.arange(5)).all()
+    pyg = out["py_grad"]
+    np.testing.assert_allclose(pyg.sum(dim=1).cpu().numpy(), 1.0, rtol=1e-4)
+    g = out["logits_grad"]
+    assert torch.isfinite(g).all() and torch.isfinite(out["pruned_loss"]).all()
+    np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=1e-6)

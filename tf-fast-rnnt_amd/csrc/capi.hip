@@ -1,0 +1,176 @@
+// csrc/capi.hip -- the extern "C" surface declared in include/ftr.h: argument validation, kernel-family
+// selection and error reporting.  No allocation, no host synchronisation, no CPU fallback.
+#include "ftr_common.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace ftr {
+namespace {
+thread_local char g_err[512] = {0};
+int g_mi_impl = -1;  // -1: not yet read from the environment
+
+int device_ok() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no usable HIP device (%s); this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return FTR_ERR_NO_DEVICE;
+  }
+  return FTR_OK;
+}
+
+int mi_impl() {
+  if (g_mi_impl < 0) {
+    const char* e = getenv("FTR_MI_IMPL");
+    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : 0;
+  }
+  return g_mi_impl;
+}
+}  // namespace
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+void clear_error() { g_err[0] = 0; }
+}  // namespace ftr
+
+using namespace ftr;
+
+#define FTR_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      set_error(__VA_ARGS__);                  \
+      return FTR_ERR_INVALID_ARG;              \
+    }                                          \
+  } while (0)
+
+extern "C" {
+
+int ftr_abi_version(void) { return 100; }
+const char* ftr_package_version(void) { return "1.2"; }
+const char* ftr_last_error(void) { return g_err; }
+
+int ftr_set_mi_impl(int impl) {
+  const int prev = mi_impl();
+  g_mi_impl = impl ? 1 : 0;
+  return prev;
+}
+int ftr_get_mi_impl(void) { return mi_impl(); }
+
+size_t ftr_mutual_information_workspace_floats(int B, int S, int T) {
+  if (B < 0 || S < 0 || T < 0) return 0;
+  return (size_t)B * (size_t)(S + 1) * (size_t)(T + 1);
+}
+
+int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary, float* p,
+                                   float* ans, int B, int S, int T, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_fwd: negative size B=%d S=%d T=%d", B, S, T);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(py && p && ans, "mutual_information_fwd: null py/p/ans");
+  FTR_REQUIRE(px || S == 0 || (modified ? T == 0 : false), "mutual_information_fwd: null px");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (mi_impl() == 1) return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
+  return mi_wave_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
+}
+
+int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32_t* boundary,
+                                   const float* p, float* p_grad, float* px_grad, float* py_grad,
+                                   float* ans_grad, int overwrite_ans_grad, int B, int S, int T,
+                                   int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_bwd: negative size B=%d S=%d T=%d", B, S, T);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(p && py_grad && ans_grad, "mutual_information_bwd: null p/py_grad/ans_grad");
+  FTR_REQUIRE(px_grad || S == 0 || (modified && T == 0), "mutual_information_bwd: null px_grad");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (mi_impl() == 1) {
+    FTR_REQUIRE(px && py, "mutual_information_bwd: the plain family needs px and py");
+    return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
+  }
+  return mi_wave_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
+}
+
+int ftr_cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows >= 0 && cols >= 0, "cummin: negative size");
+  if (rows == 0 || cols == 0) return FTR_OK;
+  FTR_REQUIRE(in && out, "cummin: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return cummin_i32(in, out, rows, cols, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_prune_ranges_i32(const float* px_grad, const float* py_grad, const int32_t* boundary,
+                         int32_t* ranges, int32_t* s_begin_scratch, int B, int S, int T, int T1,
+                         int s_range, int* r_eff_out, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 1 && T >= 1, "prune_ranges: need S >= 1 and T >= 1 (S=%d T=%d)", S, T);
+  FTR_REQUIRE(T1 == T || T1 == T + 1, "prune_ranges: px_grad last dim %d must be T or T+1 (T=%d)", T1, T);
+  FTR_REQUIRE(s_range >= 1, "prune_ranges: s_range=%d must be >= 1", s_range);
+  const int r = (s_range > S) ? S + 1 : s_range;  // rnnt_loss.py:710-711
+  if (r_eff_out) *r_eff_out = r;
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(px_grad && py_grad && boundary && ranges && s_begin_scratch, "prune_ranges: null pointer (boundary is mandatory)");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return prune_ranges(px_grad, py_grad, boundary, ranges, s_begin_scratch, B, S, T, T1, r, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, float* am_pruned,
+                       float* lm_pruned, int B, int T, int S1, int C, int r, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 0 && S1 >= 1 && C >= 0 && r >= 0, "do_pruning: bad sizes");
+  if ((size_t)B * T * r * C == 0) return FTR_OK;
+  FTR_REQUIRE(am && lm && ranges && am_pruned && lm_pruned, "do_pruning: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return do_pruning(am, lm, ranges, am_pruned, lm_pruned, B, T, S1, C, r, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_pruned_logprobs_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                const int32_t* boundary, int termination_symbol, double delay_penalty,
+                                float* lse, float* px, float* py, int B, int T, int S, int C, int r,
+                                int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 1 && C >= 1 && r >= 1, "pruned_logprobs_fwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "pruned_logprobs_fwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  FTR_REQUIRE(r <= S + 1, "pruned_logprobs_fwd: s_range %d > S+1 = %d", r, S + 1);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(logits && symbols && ranges && lse && px && py, "pruned_logprobs_fwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return pruned_logprobs_fwd(logits, symbols, ranges, boundary, termination_symbol, delay_penalty, lse, px, py, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                const int32_t* boundary, int termination_symbol, const float* lse,
+                                const float* gpx, const float* gpy, const float* scale, float* glogits,
+                                int B, int T, int S, int C, int r, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 1 && C >= 1 && r >= 1, "pruned_logprobs_bwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "pruned_logprobs_bwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(logits && symbols && ranges && lse && gpx && gpy && glogits, "pruned_logprobs_bwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return pruned_logprobs_bwd(logits, symbols, ranges, boundary, termination_symbol, lse, gpx, gpy, scale, glogits, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_selftest(void* scratch_dev, void* stream) {
+  clear_error();
+  FTR_REQUIRE(scratch_dev, "selftest: need >= 8 KiB of device scratch");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return selftest(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<int*>(scratch_dev));
+}
+
+}  // extern "C"

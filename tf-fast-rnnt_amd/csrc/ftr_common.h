@@ -1,0 +1,61 @@
+// csrc/ftr_common.h -- shared by every translation unit of libftr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ftr.h"
+
+namespace ftr {
+
+// error text of the last failing call on this thread (ftr_last_error()).
+void set_error(const char* fmt, ...);
+void clear_error();
+
+// Checks the launch that was just enqueued (no sync: hipGetLastError only reports launch-time errors).
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return FTR_ERR_LAUNCH;
+  }
+  return FTR_OK;
+}
+
+// A "minus infinity" that stays finite under the additions of the recursion, so the dependent chain
+// needs no NaN guard: anything <= NEG_THRESH is reported as -inf when it leaves a kernel.
+constexpr float kNeg = -1.0e30f;
+constexpr float kNegThresh = -1.0e29f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// 16-byte vector with 4-byte alignment: lattice rows have odd lengths (T+1), so row starts are only
+// dword aligned; amdhsa runs in unaligned-access mode and these lower to global_load/store_dwordx4.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Bound { int sb, tb, se, te; };
+__device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ boundary, int b, int S, int T) {
+  Bound r;
+  if (boundary) {
+    r.sb = boundary[4 * b + 0]; r.tb = boundary[4 * b + 1];
+    r.se = boundary[4 * b + 2]; r.te = boundary[4 * b + 3];
+  } else { r.sb = 0; r.tb = 0; r.se = S; r.te = T; }
+  return r;
+}
+
+}  // namespace ftr
+
+// launchers implemented in the kernel files (all return FTR_OK / FTR_ERR_*), called from capi.hip
+namespace ftr {
+int mi_plain_fwd(const float* px, const float* py, const int32_t* boundary, float* p, float* ans, int B, int S, int T, int modified, hipStream_t st);
+int mi_plain_bwd(const float* px, const float* py, const int32_t* boundary, const float* p, float* p_grad, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
+int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
+int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
+int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st);
+int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boundary, int32_t* ranges, int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st);
+int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1, int C, int r, hipStream_t st);
+int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
+int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, const float* scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
+int selftest(hipStream_t st, int* result_dev);
+}

@@ -1,0 +1,504 @@
+// csrc/mi_wave.hip -- "wavefront" mutual-information kernels for gfx950 (MI355X), the product path.
+//
+// What they compute is the recursion of the reference (tf_fast_rnnt/csrc/mutual_information.h:101-126,
+// mutual_information_cuda.cu:174-422 forward, :441-760 backward); HOW is different by design:
+//
+//  * one workgroup per utterance, one wave64 per 64 lattice rows, lane l <-> row s.  The wave walks the
+//    lattice in time-skewed order: at local step j lane l sits on column c = j - l (regular) or c = j
+//    (modified), so every lane's two predecessors were produced one step earlier: its own previous
+//    value (p[s,t-1]) and the neighbouring lane's previous value (p[s-1,t] / p[s-1,t-1]), fetched
+//    with one full-wave DPP shift (wave_shr:1).  The whole dependent chain of a step is
+//    mov_dpp, add, sub/max, v_exp_f32, add, v_log_f32, add -- no LDS, no barrier, no global memory.
+//    (The reference runs this part on 32 lanes of one warp per 32x32 tile and relaunches the kernel
+//    once per tile diagonal.)
+//  * values are kept in the log2 domain (inputs are multiplied by log2(e) when they are staged), so
+//    the hardware v_exp_f32 / v_log_f32 are used bare; -inf is represented by -1e30 inside the
+//    kernel so no NaN guard sits on the chain (LogAdd's "diff - diff != 0" branch,
+//    mutual_information.h:79-80, becomes unnecessary), and is turned back into -inf on the way out.
+//  * px/py are fetched with coalesced 16-byte loads (4 lanes per 64-byte row segment) two chunks of
+//    16 steps ahead into registers, then parked in a per-wave LDS tile laid out [quad][row] (plane
+//    stride 66 x 16 B) so both the fill and the per-lane ds_read_b128 are bank-conflict free.  Tiles
+//    are already skewed: lane l finds "its" four next steps at tile[q][l].
+//  * the forward does not store p.  It stores, per cell, G = sigmoid(a - b): the share of the cell's
+//    probability that arrived through the px edge.  That is exactly term1 of the incoming edge in the
+//    reference's backward (mutual_information_cuda.cu:455-457) and 1 - G is term2.  The backward then
+//    needs no exp at all: it pushes occupancy "flow" down the lattice, pg = xin + yin, xout = pg * G,
+//    yout = pg - xout; px_grad = xin, py_grad = yin (eqs. 3a-3c of the reference, .cu:474-477).  One
+//    lattice is written by the forward and one is read by the backward (the reference writes p and
+//    p_grad and reads px, py, p again), and flow is conserved to rounding.
+//  * neighbouring waves exchange their boundary row through a 64-entry LDS ring per wave pair; waves
+//    run the same chunk schedule staggered by 5 chunks (regular) or 1 (modified) with one
+//    __syncthreads() per chunk, which is what makes the ring race free (see RING below).
+//
+// Workspace ("p" in the C ABI): B*(S+1)*(T+1) floats holding G for every in-boundary cell.
+#include "ftr_common.h"
+
+namespace ftr {
+namespace {
+
+constexpr int CH = 16;              // steps per chunk
+constexpr int NQ = CH / 4;          // quads (4 consecutive steps) per chunk
+constexpr int PLANE = 66;           // float4 per [quad] plane: 64 rows + 2 pad (conflict-free fill+read)
+constexpr int TILE_F4 = NQ * PLANE; // one tile = 264 float4 = 4224 B
+constexpr int NPF = 2;              // chunks in flight in registers (prefetch distance)
+constexpr int RINGN = 64;
+
+__device__ __forceinline__ float dpp_wave_shr1(float old_for_lane0, float src) {
+  // lane l (l >= 1) receives src of lane l-1; lane 0 keeps `old_for_lane0` (bound_ctrl = 0).
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_for_lane0),
+                                                               __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+}
+
+// RING.  Wave w (the "producer") publishes, every 4 steps, the last 4 values of its lane 63 at
+// ring[w+1][(j0 & 63) .. +3], j0 = its local step.  Wave w+1 (the "consumer") needs, at ITS local step
+// j, the producer's value of local step j + 63 (regular; same column, one row up) or j - 1 (modified;
+// previous column): in both cases ring[(j - 1) & 63].  With the consumer's chunks running STG chunks
+// behind the producer's (same chunk index k executes STG slots later) every value is written at least
+// one barrier before it is read and is overwritten (64 steps later) at least two barriers after it
+// was read -- for STG = 5 (regular), 1 (modified); the arithmetic is in DESIGN.md "ring schedule".
+
+template <bool MOD>
+__global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
+    const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
+    float* __restrict__ ws, float* __restrict__ ans, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SKEW = MOD ? 0 : 1;
+  constexpr int STG = MOD ? 1 : 5;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NW = blockDim.x >> 6;
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int T1 = MOD ? T : T + 1;
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  if (Sn <= 0 || Tn <= 0) { if (threadIdx.x == 0) ans[b] = 0.0f; return; }
+
+  f4* tiles = reinterpret_cast<f4*>(smem);
+  f4* tX = tiles + (size_t)(w * 2 + 0) * TILE_F4;
+  f4* tY = tiles + (size_t)(w * 2 + 1) * TILE_F4;
+  float* rings = reinterpret_cast<float*>(tiles + (size_t)NW * 2 * TILE_F4);
+  for (int i = threadIdx.x; i < (NW + 1) * RINGN; i += blockDim.x) rings[i] = kNeg;
+  __syncthreads();
+  const f4* ring_in = reinterpret_cast<const f4*>(rings + w * RINGN);
+  f4* ring_out = reinterpret_cast<f4*>(rings + (w + 1) * RINGN);
+
+  const float* pxb = px + (size_t)b * S * T1;
+  const float* pyb = py + (size_t)b * (S + 1) * T;
+  float* wsb = ws + (size_t)b * (S + 1) * (T + 1);
+
+  const int row0 = 64 * w;
+  // staging geometry of this lane: in load/store instruction m it handles tile row 16m + (lane>>2),
+  // quad (lane & 3).
+  const int frow = lane >> 2, fq = lane & 3;
+
+  const int nchunks = (Tn + 63 * SKEW + CH - 1) / CH;
+  const int NWact = (Sn + 63) >> 6;
+  const int Gtot = nchunks + STG * (NWact - 1);
+
+  // where the answer appears: row Sn-1, column Tn-1
+  const int wfin = (Sn - 1) >> 6, lfin = (Sn - 1) & 63;
+  const int jfin = (w == wfin) ? (Tn - 1 + SKEW * lfin) : -1000;
+
+  float pcur = (w == 0 && lane == 0) ? 0.0f : kNeg;  // origin trick: p[sb,tb] = 0 + (Y := 0)
+  float ecarry = kNeg;
+
+  f4 rx[NPF][4], ry[NPF][4];
+
+  auto load_chunk = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      const int c0 = CH * k + 4 * fq - SKEW * row;  // column (relative to tb) of the quad's first step
+      f4 vx = {kNeg, kNeg, kNeg, kNeg}, vy = {kNeg, kNeg, kNeg, kNeg};
+      if (r < Sn) {
+        if (r >= 1) {  // px[s-1][t + toff], toff = -1 for modified
+          const int cx = MOD ? c0 - 1 : c0;
+          const ptrdiff_t base = (ptrdiff_t)(bd.sb + r - 1) * T1 + bd.tb + cx;
+          if (cx >= 0 && c0 + 3 < Tn) {
+            vx = *reinterpret_cast<const f4u*>(pxb + base);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cx + e >= 0 && c0 + e < Tn) vx[e] = pxb[base + e];
+          }
+        }
+        {  // py[s][t-1]
+          const ptrdiff_t base = (ptrdiff_t)(bd.sb + r) * T + bd.tb + c0 - 1;
+          if (c0 >= 1 && c0 + 3 < Tn) {
+            vy = *reinterpret_cast<const f4u*>(pyb + base);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= 1 && c0 + e < Tn) vy[e] = pyb[base + e];
+          }
+          if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e == 0) vy[e] = 0.0f;  // origin cell: b = pcur(0) + 0
+          }
+        }
+      }
+      x[m] = vx;
+      y[m] = vy;
+    }
+  };
+
+  auto write_tile = [&](const f4 (&x)[4], const f4 (&y)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      f4 xs, ys;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xs[e] = fmaxf(x[m][e] * kLog2e, kNeg);  // log2 domain; -inf (and nan) -> kNeg
+        ys[e] = fmaxf(y[m][e] * kLog2e, kNeg);
+      }
+      tX[fq * PLANE + row] = xs;
+      tY[fq * PLANE + row] = ys;
+    }
+  };
+
+  auto compute_chunk = [&](int k) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int j0 = CH * k + 4 * q;
+      const f4 X4 = tX[q * PLANE + lane];
+      const f4 Y4 = tY[q * PLANE + lane];
+      const f4 E4 = ring_in[(j0 & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
+      f4 G4, P4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ev = (e == 0) ? ecarry : E4[e - 1];
+        const float up = dpp_wave_shr1(ev, pcur);
+        const float a = up + X4[e];
+        const float c = pcur + Y4[e];
+        const float d = a - c;
+        const float mx = fmaxf(a, c);
+        const float ex = __builtin_amdgcn_exp2f(-__builtin_fabsf(d));
+        const float u = 1.0f + ex;
+        pcur = mx + __builtin_amdgcn_logf(u);
+        const float rc = __builtin_amdgcn_rcpf(u);
+        G4[e] = (d >= 0.0f) ? rc : ex * rc;
+        P4[e] = pcur;
+      }
+      ecarry = E4[3];
+      tX[q * PLANE + lane] = G4;  // in place: this slot of X has been consumed
+      if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = P4;
+      if ((jfin >> 2) == (j0 >> 2)) {  // wave-uniform
+        const int e = jfin & 3;
+        const float v = (e == 0) ? P4[0] : (e == 1) ? P4[1] : (e == 2) ? P4[2] : P4[3];
+        if (lane == lfin) ans[b] = (v <= kNegThresh) ? -INFINITY : v * kLn2;
+      }
+    }
+  };
+
+  auto store_G = [&](int k) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      if (r < Sn) {
+        const int c0 = CH * k + 4 * fq - SKEW * row;
+        const f4 g = tX[fq * PLANE + row];
+        const ptrdiff_t base = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
+        if (c0 >= 0 && c0 + 3 < Tn) {
+          *reinterpret_cast<f4u*>(wsb + base) = g;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e >= 0 && c0 + e < Tn) wsb[base + e] = g[e];
+        }
+      }
+    }
+  };
+
+  for (int g = -(NPF + 1); g < Gtot; g += NPF) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int k = g + u - STG * w;
+      if (k >= 0 && k < nchunks) {
+        if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
+        compute_chunk(k);
+        store_G(k);
+      }
+      if (k + 1 >= 0 && k + 1 < nchunks) write_tile(rx[u], ry[u]);
+      if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, rx[u], ry[u]);
+      __syncthreads();
+    }
+  }
+}
+
+// Backward on reversed coordinates: row index r = s_end - s (lane), column c = t_end - t.
+template <bool MOD>
+__global__ __launch_bounds__(1024) void mi_wave_bwd_kernel(
+    const int32_t* __restrict__ boundary, const float* __restrict__ ws, float* __restrict__ px_grad,
+    float* __restrict__ py_grad, float* __restrict__ ans_grad, int overwrite, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SKEW = MOD ? 0 : 1;
+  constexpr int STG = MOD ? 1 : 5;
+  constexpr int NOFF = MOD ? 1 : 0;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NW = blockDim.x >> 6;
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int T1 = MOD ? T : T + 1;
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  float* pxg = px_grad + (size_t)b * S * T1;
+  float* pyg = py_grad + (size_t)b * (S + 1) * T;
+
+  // ---- zeros outside the boundary rectangle (the reference memsets everything first,
+  //      tf_fast_rnnt_op.cc:93-96); the rectangle itself is fully written by the sweep below.
+  {
+    const bool empty = (Sn <= 0 || Tn <= 0);
+    // px_grad is defined on rows [sb, se) x columns [tb, te - NOFF]
+    const int xr0 = empty ? 0 : bd.sb, xr1 = empty ? 0 : bd.se;
+    const int xc0 = bd.tb, xc1 = bd.te - NOFF + 1;
+    for (int s = w; s < S; s += NW) {
+      float* row = pxg + (size_t)s * T1;
+      if (s < xr0 || s >= xr1) {
+        for (int t = lane; t < T1; t += 64) row[t] = 0.0f;
+      } else {
+        for (int t = lane; t < xc0; t += 64) row[t] = 0.0f;
+        for (int t = xc1 + lane; t < T1; t += 64) row[t] = 0.0f;
+      }
+    }
+    // py_grad is defined on rows [sb, se] x columns [tb, te)
+    const int yr0 = empty ? 0 : bd.sb, yr1 = empty ? 0 : bd.se + 1;
+    for (int s = w; s < S + 1; s += NW) {
+      float* row = pyg + (size_t)s * T;
+      if (s < yr0 || s >= yr1) {
+        for (int t = lane; t < T; t += 64) row[t] = 0.0f;
+      } else {
+        for (int t = lane; t < bd.tb; t += 64) row[t] = 0.0f;
+        for (int t = bd.te + lane; t < T; t += 64) row[t] = 0.0f;
+      }
+    }
+    if (empty) return;
+  }
+
+  f4* tiles = reinterpret_cast<f4*>(smem);
+  f4* tG = tiles + (size_t)(w * 2 + 0) * TILE_F4;  // G in, px_grad quads out (in place)
+  f4* tO = tiles + (size_t)(w * 2 + 1) * TILE_F4;  // py_grad quads out
+  float* rings = reinterpret_cast<float*>(tiles + (size_t)NW * 2 * TILE_F4);
+  for (int i = threadIdx.x; i < (NW + 1) * RINGN; i += blockDim.x) rings[i] = 0.0f;
+  __syncthreads();
+  const f4* ring_in = reinterpret_cast<const f4*>(rings + w * RINGN);
+  f4* ring_out = reinterpret_cast<f4*>(rings + (w + 1) * RINGN);
+
+  const float* wsb = ws + (size_t)b * (S + 1) * (T + 1);
+  const int row0 = 64 * w;
+  const int frow = lane >> 2, fq = lane & 3;
+  const int nchunks = (Tn + 63 * SKEW + CH - 1) / CH;
+  const int NWact = (Sn + 63) >> 6;
+  const int Gtot = nchunks + STG * (NWact - 1);
+  const int wfin = (Sn - 1) >> 6, lfin = (Sn - 1) & 63;
+  const int jfin = (w == wfin) ? (Tn - 1 + SKEW * lfin) : -1000;  // where p_grad[sb,tb] appears
+
+  float yprev = (w == 0 && lane == 0) ? ans_grad[b] : 0.0f;  // seeds p_grad[se,te] = ans_grad
+  float xprev = 0.0f;
+  float ecarry = 0.0f;
+  f4 rg[NPF][4];
+
+  auto load_chunk = [&](int k, f4 (&gq)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      const int c0 = CH * k + 4 * fq - SKEW * row;
+      f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (r < Sn) {
+        // element e is column c0+e reversed: t = te - c0 - e; memory order is the reverse of e.
+        const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
+        if (c0 >= 0 && c0 + 3 < Tn) {
+          const f4 t4 = *reinterpret_cast<const f4u*>(wsb + lo);
+          v[0] = t4[3]; v[1] = t4[2]; v[2] = t4[1]; v[3] = t4[0];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e >= 0 && c0 + e < Tn) v[e] = wsb[lo + 3 - e];
+        }
+      }
+      gq[m] = v;
+    }
+  };
+
+  auto write_tile = [&](const f4 (&gq)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) tG[fq * PLANE + 16 * m + frow] = gq[m];
+  };
+
+  auto compute_chunk = [&](int k) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int j0 = CH * k + 4 * q;
+      const f4 G4 = tG[q * PLANE + lane];
+      const f4 E4 = ring_in[(j0 & (RINGN - 1)) >> 2];
+      f4 XO4, PX4, PY4, PG4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ev = (e == 0) ? ecarry : E4[e - 1];
+        const float xin = dpp_wave_shr1(ev, xprev);
+        const float pg = xin + yprev;
+        PX4[e] = xin;    // px_grad[s,t]  = p_grad[s+1,t(+1)] * term1(s,t)   (3b)
+        PY4[e] = yprev;  // py_grad[s,t]  = p_grad[s,t+1]     * term2(s,t)   (3c)
+        PG4[e] = pg;     // p_grad[s,t]                                     (3a)
+        xprev = pg * G4[e];
+        yprev = pg - xprev;
+        XO4[e] = xprev;
+      }
+      ecarry = E4[3];
+      tG[q * PLANE + lane] = PX4;
+      tO[q * PLANE + lane] = PY4;
+      if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = XO4;
+      if (overwrite && (jfin >> 2) == (j0 >> 2)) {
+        const int e = jfin & 3;
+        const float v = (e == 0) ? PG4[0] : (e == 1) ? PG4[1] : (e == 2) ? PG4[2] : PG4[3];
+        if (lane == lfin) ans_grad[b] = v;
+      }
+    }
+  };
+
+  auto store_out = [&](int k) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      if (r < Sn) {
+        const int c0 = CH * k + 4 * fq - SKEW * row;
+        const int s = bd.se - r;
+        const f4 gx = tG[fq * PLANE + row];
+        const f4 gy = tO[fq * PLANE + row];
+        if (r >= 1) {  // px_grad rows are s < se; columns c in [NOFF, Tn)
+          const ptrdiff_t lo = (ptrdiff_t)s * T1 + bd.te - c0 - 3;
+          if (c0 >= NOFF && c0 + 3 < Tn) {
+            f4 o; o[0] = gx[3]; o[1] = gx[2]; o[2] = gx[1]; o[3] = gx[0];
+            *reinterpret_cast<f4u*>(pxg + lo) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= NOFF && c0 + e < Tn) pxg[lo + 3 - e] = gx[e];
+          }
+        }
+        {  // py_grad columns t < te  <=>  c >= 1
+          const ptrdiff_t lo = (ptrdiff_t)s * T + bd.te - c0 - 3;
+          if (c0 >= 1 && c0 + 3 < Tn) {
+            f4 o; o[0] = gy[3]; o[1] = gy[2]; o[2] = gy[1]; o[3] = gy[0];
+            *reinterpret_cast<f4u*>(pyg + lo) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= 1 && c0 + e < Tn) pyg[lo + 3 - e] = gy[e];
+          }
+        }
+      }
+    }
+  };
+
+  for (int g = -(NPF + 1); g < Gtot; g += NPF) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int k = g + u - STG * w;
+      if (k >= 0 && k < nchunks) {
+        if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
+        compute_chunk(k);
+        store_out(k);
+      }
+      if (k + 1 >= 0 && k + 1 < nchunks) write_tile(rg[u]);
+      if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, rg[u]);
+      __syncthreads();
+    }
+  }
+}
+
+inline size_t wave_lds_bytes(int NW) {
+  return (size_t)NW * 2 * TILE_F4 * sizeof(f4) + (size_t)(NW + 1) * RINGN * sizeof(float);
+}
+
+template <typename K>
+int prepare_lds(K kernel, size_t lds, const char* what) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("%s: cannot reserve %zu bytes of LDS: %s", what, lds, hipGetErrorString(e));
+      return FTR_ERR_LAUNCH;
+    }
+  }
+  return FTR_OK;
+}
+
+}  // namespace
+
+int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans,
+                int B, int S, int T, int modified, hipStream_t st) {
+  const int NW = (S + 1 + 63) / 64;
+  if (NW > 16) {
+    set_error("mi_wave_fwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
+    return FTR_ERR_UNSUPPORTED;
+  }
+  const size_t lds = wave_lds_bytes(NW);
+  int rc;
+  if (modified) {
+    if ((rc = prepare_lds(mi_wave_fwd_kernel<true>, lds, "mi_wave_fwd")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(mi_wave_fwd_kernel<true>, dim3(B), dim3(64 * NW), lds, st, px, py, boundary, ws, ans, S, T);
+  } else {
+    if ((rc = prepare_lds(mi_wave_fwd_kernel<false>, lds, "mi_wave_fwd")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(mi_wave_fwd_kernel<false>, dim3(B), dim3(64 * NW), lds, st, px, py, boundary, ws, ans, S, T);
+  }
+  return check_launch("mi_wave_fwd");
+}
+
+int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad,
+                float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st) {
+  const int NW = (S + 1 + 63) / 64;
+  if (NW > 16) {
+    set_error("mi_wave_bwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
+    return FTR_ERR_UNSUPPORTED;
+  }
+  const size_t lds = wave_lds_bytes(NW);
+  int rc;
+  if (modified) {
+    if ((rc = prepare_lds(mi_wave_bwd_kernel<true>, lds, "mi_wave_bwd")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(mi_wave_bwd_kernel<true>, dim3(B), dim3(64 * NW), lds, st, boundary, ws, px_grad, py_grad, ans_grad, overwrite, S, T);
+  } else {
+    if ((rc = prepare_lds(mi_wave_bwd_kernel<false>, lds, "mi_wave_bwd")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(mi_wave_bwd_kernel<false>, dim3(B), dim3(64 * NW), lds, st, boundary, ws, px_grad, py_grad, ans_grad, overwrite, S, T);
+  }
+  return check_launch("mi_wave_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hardware self-test: the wavefront kernels rely on (1) wave_shr:1 DPP shifting across all 64 lanes
+// with lane 0 keeping `old`, (2) 16-byte global loads/stores at 4-byte alignment.  result[0] = 1 if
+// both behave as assumed.
+__global__ void selftest_kernel(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ result) {
+  const int lane = threadIdx.x;
+  const float mine = (float)(lane + 1);
+  const float got = dpp_wave_shr1(-7.0f, mine);
+  const bool ok1 = (lane == 0) ? (got == -7.0f) : (got == (float)lane);
+  // unaligned 16B load at element offset 1 + 5*lane, store at 3 + 5*lane
+  const f4 v = *reinterpret_cast<const f4u*>(in + 1 + 5 * lane);
+  bool ok2 = true;
+  for (int e = 0; e < 4; ++e) ok2 = ok2 && (v[e] == (float)(1 + 5 * lane + e));
+  *reinterpret_cast<f4u*>(out + 3 + 5 * lane) = v;
+  const unsigned long long m = __ballot(ok1 && ok2);
+  if (lane == 0) result[0] = (m == ~0ull) ? 1 : 0;
+}
+
+int selftest(hipStream_t st, int* result_dev) {
+  // scratch lives behind result_dev: [0] result int, then 512 floats in, 512 floats out
+  float* in = reinterpret_cast<float*>(result_dev + 4);
+  float* out = in + 512;
+  float host[512];
+  for (int i = 0; i < 512; ++i) host[i] = (float)i;
+  if (hipMemcpyAsync(in, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) {
+    set_error("selftest: memcpy failed"); return FTR_ERR_LAUNCH;
+  }
+  hipStreamSynchronize(st);  // host[] is on the stack
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, in, out, result_dev);
+  return check_launch("selftest");
+}
+
+}  // namespace ftr

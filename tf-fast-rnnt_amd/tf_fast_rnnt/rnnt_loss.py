@@ -1,0 +1,532 @@
+"""The Python op surface of tf_fast_rnnt on MI355X: same names, keyword signatures, defaults and return
+conventions as the reference's ``tf_fast_rnnt/python/tf_fast_rnnt/rnnt_loss.py`` (cited per function
+as ``rnnt_loss.py:<lines>``), on torch tensors resident in HBM.
+
+What runs where:
+* ``mutual_information_recursion`` (every loss ends there), ``get_rnnt_prune_ranges``,
+  ``do_rnnt_pruning``, ``get_rnnt_logprobs_pruned`` / ``rnnt_loss_pruned``: hand-written HIP behind the
+  C ABI (include/ftr.h);
+* the simple / smoothed / joint px,py builders: torch ops for now (normaliser contraction through
+  rocBLAS) -- SURVEY.md 8(f) row 1, "next".
+
+Reference bugs that are NOT reproduced: ``rnnt_loss_simple(reduction="mean")``
+raises NameError there (rnnt_loss.py:331) -- here it is the mean; ``boundary=None`` works; the
+non-regular ``rnnt_type`` values do not hit the shape error of rnnt_loss.py:211/440/1324 (the
+normalisers are used unpadded, as upstream k2 does).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import _lib
+from .mutual_information import (_as_boundary, _ptr, _require_gpu, _stream_ptr, cummin,
+                                 mi_forward_backward, mutual_information_recursion)
+
+_NEG_INF = float("-inf")
+# tf.math.nextafter(0., 1.) : smallest positive float32 subnormal (rnnt_loss.py:181,1272,1280)
+_TINY = 1.401298464324817e-45
+
+
+def _check_type(rnnt_type: str) -> None:
+    if rnnt_type not in ("regular", "modified", "constrained"):
+        raise ValueError(f"rnnt_type should be ('regular' | 'modified' | 'constrained'), given {rnnt_type}")
+
+
+def _i64(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int64 else t.to(torch.int64)
+
+
+def fix_for_boundary(px: torch.Tensor, boundary: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rnnt_loss.py:28-61: px[b, :, boundary[b,3]] = -inf (regular type only)."""
+    if boundary is None:
+        return px
+    B, S, T1 = px.shape
+    idx = _i64(boundary[:, 3]).reshape(B, 1, 1).expand(B, S, 1)
+    return px.scatter(2, idx, _NEG_INF)
+
+
+def _normalizers(lm: torch.Tensor, am: torch.Tensor):
+    """rnnt_loss.py:175-186."""
+    am_max = am.max(dim=2, keepdim=True).values            # [B,T,1]
+    lm_max = lm.max(dim=2, keepdim=True).values            # [B,S+1,1]
+    am_probs = (am - am_max).exp()
+    lm_probs = (lm - lm_max).exp()
+    normalizers = (torch.matmul(lm_probs, am_probs.transpose(1, 2)) + _TINY).log()
+    normalizers = normalizers + lm_max + am_max.transpose(1, 2)   # [B,S+1,T]
+    return normalizers, am_max, lm_max, am_probs, lm_probs
+
+
+def get_rnnt_logprobs(
+    lm: torch.Tensor,
+    am: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    rnnt_type: str = "regular",
+    boundary: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:63-223.  lm [B,S+1,C], am [B,T,C], symbols [B,S] -> px [B,S,T+1|T], py [B,S+1,T]."""
+    _check_type(rnnt_type)
+    B, T, C = am.shape
+    S = lm.shape[1] - 1
+    if tuple(symbols.shape) != (B, S):
+        raise ValueError(f"symbols must have shape {(B, S)}, got {tuple(symbols.shape)}")
+    sym = _i64(symbols)
+    normalizers, *_ = _normalizers(lm, am)
+    # px_am[b,s,t] = am[b,t,symbols[b,s]]                                   (:187-192)
+    px_am = torch.gather(am.transpose(1, 2), 1, sym.unsqueeze(2).expand(B, S, T))
+    if rnnt_type == "regular":
+        px_am = torch.cat((px_am, torch.full((B, S, 1), _NEG_INF, dtype=am.dtype, device=am.device)), dim=2)
+    px_lm = torch.gather(lm[:, :S, :], 2, sym.unsqueeze(2))                  # [B,S,1]   (:204-207)
+    px = px_am + px_lm
+    if rnnt_type == "regular":
+        px = px - torch.cat((normalizers, torch.zeros((B, S + 1, 1), dtype=am.dtype, device=am.device)), dim=2)[:, :S, :]
+    else:
+        px = px - normalizers[:, :S, :]
+    py_am = am[:, :, termination_symbol].unsqueeze(1)                        # [B,1,T]
+    py_lm = lm[:, :, termination_symbol].unsqueeze(2)                        # [B,S+1,1]
+    py = py_am + py_lm - normalizers
+    if rnnt_type == "regular":
+        px = fix_for_boundary(px, boundary)
+    elif rnnt_type == "constrained":
+        px = px + py[:, 1:, :]
+    return px, py
+
+
+def _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty):
+    """rnnt_loss.py:305-321 (also :518-534, :1097-1114, :1461-1478): float64 offsets, cast to px.dtype."""
+    if not delay_penalty > 0.0:
+        return px
+    B, S, T0 = px.shape
+    T = T0 if rnnt_type != "regular" else T0 - 1
+    if boundary is None:
+        offset = torch.full((B,), (T - 1) / 2, dtype=torch.float64, device=px.device)
+    else:
+        offset = (boundary[:, 3].to(torch.float64) - 1) / 2
+    penalty = offset.reshape(B, 1, 1) - torch.arange(T0, dtype=torch.float64, device=px.device).reshape(1, 1, T0)
+    penalty = penalty * delay_penalty
+    return px + penalty.to(px.dtype)
+
+
+def _reduce(negated_loss: torch.Tensor, reduction: Optional[str]) -> torch.Tensor:
+    if reduction == "none":
+        return -negated_loss
+    if reduction == "mean":
+        return -torch.mean(negated_loss)
+    if reduction == "sum":
+        return -torch.sum(negated_loss)
+    raise ValueError(f"reduction should be ('none' | 'mean' | 'sum'), given {reduction}")
+
+
+def _drive(px, py, boundary, reduction, calc_gradients):
+    scores_and_grads = mutual_information_recursion(px=px, py=py, boundary=boundary, calc_gradients=calc_gradients)
+    negated_loss = scores_and_grads[0] if calc_gradients else scores_and_grads
+    loss = _reduce(negated_loss, reduction)
+    return (loss, scores_and_grads[1]) if calc_gradients else loss
+
+
+def rnnt_loss_simple(
+    lm: torch.Tensor,
+    am: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+    delay_penalty: float = 0.0,
+    reduction: Optional[str] = "mean",
+    calc_gradients: bool = False,
+) -> Union[torch.Tensor, Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]]:
+    """rnnt_loss.py:225-338.  Returns loss, or (loss, (px_grad, py_grad)) when ``calc_gradients``."""
+    boundary = _as_boundary(boundary, am.shape[0], am.device)
+    px, py = get_rnnt_logprobs(lm=lm, am=am, symbols=symbols, termination_symbol=termination_symbol,
+                               boundary=boundary, rnnt_type=rnnt_type)
+    px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
+    return _drive(px, py, boundary, reduction, calc_gradients)
+
+
+def get_rnnt_logprobs_joint(
+    logits: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:340-452.  logits [B,T,S+1,C] -> px, py."""
+    _check_type(rnnt_type)
+    B, T, S1, C = logits.shape
+    S = S1 - 1
+    sym = _i64(symbols)
+    normalizers = torch.logsumexp(logits, dim=3).permute(0, 2, 1)            # [B,S+1,T]
+    px = torch.gather(logits[:, :, :S, :], 3, sym.reshape(B, 1, S, 1).expand(B, T, S, 1)).squeeze(-1)
+    px = px.permute(0, 2, 1)                                                  # [B,S,T]
+    if rnnt_type == "regular":
+        px = torch.cat((px, torch.full((B, S, 1), _NEG_INF, dtype=logits.dtype, device=logits.device)), dim=2)
+        px = px - torch.cat((normalizers, torch.zeros((B, S + 1, 1), dtype=logits.dtype, device=logits.device)), dim=2)[:, :S, :]
+    else:
+        px = px - normalizers[:, :S, :]
+    py = logits[:, :, :, termination_symbol].permute(0, 2, 1) - normalizers
+    if rnnt_type == "regular":
+        px = fix_for_boundary(px, boundary)
+    elif rnnt_type == "constrained":
+        px = px + py[:, 1:, :]
+    return px.contiguous(), py.contiguous()
+
+
+def rnnt_loss(
+    logits: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+    delay_penalty: float = 0.0,
+    reduction: Optional[str] = "mean",
+    calc_gradients: bool = False,
+) -> torch.Tensor:
+    """rnnt_loss.py:454-551 (unpruned loss on joiner logits [B,T,S+1,C])."""
+    boundary = _as_boundary(boundary, logits.shape[0], logits.device)
+    px, py = get_rnnt_logprobs_joint(logits=logits, symbols=symbols, termination_symbol=termination_symbol,
+                                     boundary=boundary, rnnt_type=rnnt_type)
+    px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
+    return _drive(px, py, boundary, reduction, calc_gradients)
+
+
+def _monotonic_lower_bound(x: torch.Tensor) -> torch.Tensor:
+    """rnnt_loss.py:553-585: reverse -> cummin -> reverse (suffix minimum).  int32, last axis."""
+    squeeze = x.dim() == 1
+    x2 = x.reshape(1, -1) if squeeze else x
+    out = cummin(torch.flip(x2.to(torch.int32), dims=(-1,)).contiguous())
+    out = torch.flip(out, dims=(-1,))
+    return out[0] if squeeze else out
+
+
+def _adjust_pruning_lower_bound(s_begin: torch.Tensor, s_range: int) -> torch.Tensor:
+    """rnnt_loss.py:587-641, op by op on top of the native ``cummin`` (the fused path used by
+    ``get_rnnt_prune_ranges`` does the same arithmetic in one kernel)."""
+    B, T = s_begin.shape
+    ar = torch.arange(0, T, dtype=torch.int32, device=s_begin.device)
+    s_begin = _monotonic_lower_bound(s_begin)
+    s_begin = -(s_begin - (s_range - 1) * ar)
+    s_begin = _monotonic_lower_bound(s_begin)
+    s_begin = torch.clamp(s_begin, min=0)
+    s_begin = -(s_begin - (s_range - 1) * ar)
+    return s_begin
+
+
+def get_rnnt_prune_ranges(
+    px_grad: torch.Tensor,
+    py_grad: torch.Tensor,
+    boundary: torch.Tensor,
+    s_range: int,
+) -> torch.Tensor:
+    """rnnt_loss.py:647-761.  Returns int32 ranges [B,T,s_range'] with s_range' = S+1 if s_range > S."""
+    _require_gpu(px_grad, "px_grad"); _require_gpu(py_grad, "py_grad")
+    B, S, T1 = px_grad.shape
+    T = py_grad.shape[-1]
+    if T1 not in (T, T + 1):
+        raise ValueError(f"px_grad.shape[-1]={T1} must be T or T+1 (T={T})")
+    if tuple(py_grad.shape) != (B, S + 1, T):
+        raise ValueError(f"py_grad must have shape {(B, S + 1, T)}, got {tuple(py_grad.shape)}")
+    if boundary is None:
+        raise ValueError("get_rnnt_prune_ranges: boundary is mandatory (rnnt_loss.py:741-746)")
+    s_range = int(s_range)
+    r = S + 1 if s_range > S else s_range
+    px_grad = px_grad.detach().to(torch.float32).contiguous()
+    py_grad = py_grad.detach().to(torch.float32).contiguous()
+    boundary = _as_boundary(boundary, B, px_grad.device)
+    ranges = torch.empty((B, T, r), dtype=torch.int32, device=px_grad.device)
+    scratch = torch.empty((B, T), dtype=torch.int32, device=px_grad.device)
+    import ctypes
+    r_eff = ctypes.c_int(0)
+    with torch.cuda.device(px_grad.device):
+        _lib.call("ftr_prune_ranges_i32", _ptr(px_grad), _ptr(py_grad), _ptr(boundary), _ptr(ranges),
+                                                   _ptr(scratch), B, S, T, T1, s_range, ctypes.byref(r_eff),
+                                                   _stream_ptr(px_grad))
+    assert r_eff.value == r
+    return ranges
+
+
+class _DoPruning(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, am, lm, ranges):
+        B, T, r = ranges.shape
+        S1, C = lm.shape[1], lm.shape[2]
+        am_c = am.detach().contiguous(); lm_c = lm.detach().contiguous()
+        am_p = torch.empty((B, T, r, C), dtype=am.dtype, device=am.device)
+        lm_p = torch.empty((B, T, r, C), dtype=lm.dtype, device=lm.device)
+        with torch.cuda.device(am.device):
+            _lib.call("ftr_do_pruning_f32", _ptr(am_c), _ptr(lm_c), _ptr(ranges), _ptr(am_p), _ptr(lm_p),
+                                                     B, T, S1, C, r, _stream_ptr(am))
+        ctx.save_for_backward(ranges)
+        ctx.lm_shape = tuple(lm.shape)
+        return am_p, lm_p
+
+    @staticmethod
+    def backward(ctx, g_am_p, g_lm_p):
+        (ranges,) = ctx.saved_tensors
+        B, S1, C = ctx.lm_shape
+        g_am = g_am_p.sum(dim=2)                                             # broadcast  <-> sum over s_range
+        g_lm = torch.zeros((B, S1, C), dtype=g_lm_p.dtype, device=g_lm_p.device)
+        idx = _i64(ranges).reshape(B, -1, 1).expand(B, ranges.shape[1] * ranges.shape[2], C)
+        g_lm.scatter_add_(1, idx, g_lm_p.reshape(B, -1, C))                   # gather     <-> scatter-add
+        return g_am, g_lm, None
+
+
+def do_rnnt_pruning(am: torch.Tensor, lm: torch.Tensor, ranges: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:763-812.  am [B,T,C], lm [B,S+1,C], ranges [B,T,s_range] -> two [B,T,s_range,C]."""
+    _require_gpu(am, "am"); _require_gpu(lm, "lm"); _require_gpu(ranges, "ranges")
+    if am.dtype != torch.float32 or lm.dtype != torch.float32:
+        raise TypeError("am and lm must be float32")
+    if ranges.shape[0] != am.shape[0] or ranges.shape[0] != lm.shape[0] or am.shape[1] != ranges.shape[1]:
+        raise ValueError("do_rnnt_pruning: inconsistent shapes")
+    ranges = ranges.to(torch.int32).contiguous()
+    return _DoPruning.apply(am, lm, ranges)
+
+
+def _roll_by_shifts(src: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
+    """rnnt_loss.py:814-851: out[b,t,i] = src[b,t,(i - shifts[b,t]) % S]."""
+    B, T, S = src.shape
+    index = (torch.arange(S, device=src.device).reshape(1, 1, S) - _i64(shifts).reshape(B, T, 1)) % S
+    return torch.gather(src, 2, index)
+
+
+class _PrunedLogprobs(torch.autograd.Function):
+    """get_rnnt_logprobs_pruned for regular/modified as two native launches each way."""
+
+    @staticmethod
+    def forward(ctx, logits, symbols, ranges, termination_symbol, boundary, modified, delay_penalty):
+        B, T, r, C = logits.shape
+        S = symbols.shape[1]
+        T1 = T if modified else T + 1
+        x = logits.detach().contiguous()
+        lse = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
+        px = torch.empty((B, S, T1), dtype=torch.float32, device=x.device)
+        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("ftr_pruned_logprobs_fwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary),
+                                                              int(termination_symbol), float(delay_penalty), _ptr(lse),
+                                                              _ptr(px), _ptr(py), B, T, S, C, r, int(modified),
+                                                              _stream_ptr(x))
+        ctx.save_for_backward(x, symbols, ranges, lse, boundary if boundary is not None else torch.empty(0))
+        ctx.has_boundary = boundary is not None
+        ctx.meta = (int(termination_symbol), int(modified))
+        return px, py
+
+    @staticmethod
+    def backward(ctx, gpx, gpy):
+        x, symbols, ranges, lse, boundary = ctx.saved_tensors
+        if not ctx.has_boundary:
+            boundary = None
+        blank, modified = ctx.meta
+        B, T, r, C = x.shape
+        S = symbols.shape[1]
+        g = torch.empty_like(x)
+        gpx = gpx.contiguous(); gpy = gpy.contiguous()
+        with torch.cuda.device(x.device):
+            _lib.call("ftr_pruned_logprobs_bwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary), blank,
+                                                              _ptr(lse), _ptr(gpx), _ptr(gpy), None, _ptr(g),
+                                                              B, T, S, C, r, modified, _stream_ptr(x))
+        return g, None, None, None, None, None, None
+
+
+def _pruned_inputs(logits, symbols, ranges, boundary):
+    _require_gpu(logits, "logits")
+    if logits.dim() != 4:
+        raise ValueError("logits must be [B,T,s_range,C]")
+    if logits.dtype != torch.float32:
+        raise TypeError("logits must be float32")
+    B, T, r, C = logits.shape
+    symbols = torch.as_tensor(symbols, device=logits.device).to(torch.int32).contiguous()
+    ranges = torch.as_tensor(ranges, device=logits.device).to(torch.int32).contiguous()
+    if tuple(ranges.shape) != (B, T, r):
+        raise ValueError(f"ranges must have shape {(B, T, r)}, got {tuple(ranges.shape)}")
+    if symbols.dim() != 2 or symbols.shape[0] != B:
+        raise ValueError("symbols must be [B,S]")
+    boundary = _as_boundary(boundary, B, logits.device)
+    return symbols, ranges, boundary
+
+
+def get_rnnt_logprobs_pruned(
+    logits: torch.Tensor,
+    symbols: torch.Tensor,
+    ranges: torch.Tensor,
+    termination_symbol: int,
+    boundary: torch.Tensor,
+    rnnt_type: str = "regular",
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:853-1020.  logits [B,T,s_range,C] -> full-size px [B,S,T+1|T], py [B,S+1,T] with
+    -inf outside the pruned band."""
+    _check_type(rnnt_type)
+    symbols, ranges, boundary = _pruned_inputs(logits, symbols, ranges, boundary)
+    modified = rnnt_type != "regular"
+    px, py = _PrunedLogprobs.apply(logits, symbols, ranges, termination_symbol, boundary, modified, 0.0)
+    if rnnt_type == "constrained":
+        px = px + py[:, 1:, :]
+    return px, py
+
+
+class _PrunedLoss(torch.autograd.Function):
+    """rnnt_loss_pruned for regular/modified with the whole chain native: logsumexp + band->lattice,
+    recursion forward, recursion backward (occupancies), and in backward() one streaming kernel that
+    turns occupancies * upstream gradient into d loss / d logits (fusing _RNNTLossGrad,
+    __init__.py:154-162, into the softmax-gradient writer)."""
+
+    @staticmethod
+    def forward(ctx, logits, symbols, ranges, termination_symbol, boundary, modified, delay_penalty):
+        B, T, r, C = logits.shape
+        S = symbols.shape[1]
+        T1 = T if modified else T + 1
+        x = logits.detach().contiguous()
+        need = logits.requires_grad
+        lse = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
+        px = torch.empty((B, S, T1), dtype=torch.float32, device=x.device)
+        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call("ftr_pruned_logprobs_fwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary),
+                                                              int(termination_symbol), float(delay_penalty), _ptr(lse),
+                                                              _ptr(px), _ptr(py), B, T, S, C, r, int(modified),
+                                                              _stream_ptr(x))
+        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need)
+        del px, py
+        if need:
+            ctx.save_for_backward(x, symbols, ranges, lse, px_grad, py_grad,
+                                  boundary if boundary is not None else torch.empty(0))
+        ctx.has_boundary = boundary is not None
+        ctx.meta = (int(termination_symbol), int(modified))
+        return ans
+
+    @staticmethod
+    def backward(ctx, g_ans):
+        x, symbols, ranges, lse, px_grad, py_grad, boundary = ctx.saved_tensors
+        if not ctx.has_boundary:
+            boundary = None
+        blank, modified = ctx.meta
+        B, T, r, C = x.shape
+        S = symbols.shape[1]
+        g = torch.empty_like(x)
+        scale = g_ans.to(torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            _lib.call("ftr_pruned_logprobs_bwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary), blank,
+                                                              _ptr(lse), _ptr(px_grad), _ptr(py_grad), _ptr(scale), _ptr(g),
+                                                              B, T, S, C, r, modified, _stream_ptr(x))
+        return g, None, None, None, None, None, None
+
+
+def rnnt_loss_pruned(
+    logits: torch.Tensor,
+    symbols: torch.Tensor,
+    ranges: torch.Tensor,
+    termination_symbol: int,
+    boundary: torch.Tensor = None,
+    rnnt_type: str = "regular",
+    delay_penalty: float = 0.0,
+    reduction: Optional[str] = "mean",
+    calc_gradients: bool = False,
+) -> torch.Tensor:
+    """rnnt_loss.py:1022-1130.  Returns the loss only (``calc_gradients`` is accepted and, as in the
+    reference, only selects whether the op computes occupancies; here that follows ``requires_grad``)."""
+    _check_type(rnnt_type)
+    if reduction not in ("none", "mean", "sum"):
+        raise ValueError(f"reduction should be ('none' | 'mean' | 'sum'), given {reduction}")
+    symbols_i, ranges_i, boundary_i = _pruned_inputs(logits, symbols, ranges, boundary)
+    if rnnt_type == "constrained":
+        px, py = get_rnnt_logprobs_pruned(logits=logits, symbols=symbols_i, ranges=ranges_i,
+                                          termination_symbol=termination_symbol, boundary=boundary_i, rnnt_type=rnnt_type)
+        px = _apply_delay_penalty(px, boundary_i, rnnt_type, delay_penalty)
+        negated_loss = mutual_information_recursion(px=px, py=py, boundary=boundary_i, calc_gradients=False)
+    else:
+        negated_loss = _PrunedLoss.apply(logits, symbols_i, ranges_i, termination_symbol, boundary_i,
+                                         rnnt_type != "regular", float(delay_penalty) if delay_penalty > 0.0 else 0.0)
+    return _reduce(negated_loss, reduction)
+
+
+def get_rnnt_logprobs_smoothed(
+    lm: torch.Tensor,
+    am: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    lm_only_scale: float = 0.1,
+    am_only_scale: float = 0.1,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+    process_group=None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:1132-1367.  ``process_group`` (extension, default None = local batch only): when the
+    batch is sharded over ranks, the batch-wide ``unigram_lm`` mean (rnnt_loss.py:1279-1280) is
+    all-reduced (one [C] vector over RCCL, differentiable) so every shard sees the global-batch value."""
+    _check_type(rnnt_type)
+    B, T, C = am.shape
+    S = lm.shape[1] - 1
+    sym = _i64(symbols)
+    normalizers, am_max, lm_max, am_probs, lm_probs = _normalizers(lm, am)
+    lmonly_normalizers = lm_probs.sum(dim=2, keepdim=True)                    # [B,S+1,1]   (:1276-1278)
+    ratio_sum = (lm_probs / lmonly_normalizers).sum(dim=(0, 1), keepdim=True)  # [1,1,C]
+    count = float(B * (S + 1))
+    if process_group is not None:
+        from .distributed import all_reduce_sum_differentiable
+        ratio_sum = all_reduce_sum_differentiable(ratio_sum, process_group)
+        count = count * torch.distributed.get_world_size(process_group)
+    unigram_lm = ratio_sum / count + _TINY                                    # (:1279-1280)
+    amonly_normalizers = (torch.mv(am_probs.reshape(-1, C), unigram_lm.reshape(C)).log().reshape(B, T, 1) + am_max)
+    amonly_normalizers = amonly_normalizers.transpose(1, 2)                   # [B,1,T]     (:1281-1286)
+    unigram_lm = unigram_lm.log()
+    lmonly_normalizers = lmonly_normalizers.log() + lm_max                    # [B,S+1,1]   (:1288-1290)
+
+    px_am = torch.gather(am.transpose(1, 2), 1, sym.unsqueeze(2).expand(B, S, T))
+    regular = rnnt_type == "regular"
+    if regular:
+        px_am = torch.cat((px_am, torch.full((B, S, 1), _NEG_INF, dtype=am.dtype, device=am.device)), dim=2)
+    px_lm = torch.gather(lm[:, :S, :], 2, sym.unsqueeze(2))                   # [B,S,1]
+    px_lm_unigram = unigram_lm.reshape(-1)[sym].unsqueeze(2)                   # [B,S,1]     (:1319-1321)
+    px = px_am + px_lm
+    if regular:
+        px = px - torch.cat((normalizers, torch.zeros((B, S + 1, 1), dtype=am.dtype, device=am.device)), dim=2)[:, :S, :]
+        px_amonly = (px_am + px_lm_unigram) - torch.cat(
+            (amonly_normalizers, torch.zeros((B, 1, 1), dtype=am.dtype, device=am.device)), dim=2)
+    else:
+        px = px - normalizers[:, :S, :]
+        px_amonly = (px_am + px_lm_unigram) - amonly_normalizers
+    px_lmonly = px_lm - lmonly_normalizers[:, :S, :]
+
+    py_am = am[:, :, termination_symbol].unsqueeze(1)
+    py_lm = lm[:, :, termination_symbol].unsqueeze(2)
+    py = py_am + py_lm - normalizers
+    py_lm_unigram = unigram_lm[0][0][termination_symbol]
+    py_amonly = py_am + py_lm_unigram - amonly_normalizers
+    py_lmonly = py_lm - lmonly_normalizers
+
+    combined_scale = 1.0 - lm_only_scale - am_only_scale
+    if lm_only_scale == 0.0:
+        lm_only_scale = 1.0e-20
+    if am_only_scale == 0.0:
+        am_only_scale = 1.0e-20
+    px_interp = px * combined_scale + px_lmonly * lm_only_scale + px_amonly * am_only_scale
+    py_interp = py * combined_scale + py_lmonly * lm_only_scale + py_amonly * am_only_scale
+    if regular:
+        px_interp = fix_for_boundary(px_interp, boundary)
+    elif rnnt_type == "constrained":
+        px_interp = px_interp + py_interp[:, 1:, :]
+    return px_interp, py_interp
+
+
+def rnnt_loss_smoothed(
+    lm: torch.Tensor,
+    am: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    lm_only_scale: float = 0.1,
+    am_only_scale: float = 0.1,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+    delay_penalty: float = 0.0,
+    reduction: Optional[str] = "mean",
+    calc_gradients: bool = False,
+    process_group=None,
+) -> Union[Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]], torch.Tensor]:
+    """rnnt_loss.py:1369-1494."""
+    boundary = _as_boundary(boundary, am.shape[0], am.device)
+    px, py = get_rnnt_logprobs_smoothed(lm=lm, am=am, symbols=symbols, termination_symbol=termination_symbol,
+                                        lm_only_scale=lm_only_scale, am_only_scale=am_only_scale,
+                                        boundary=boundary, rnnt_type=rnnt_type, process_group=process_group)
+    px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
+    return _drive(px, py, boundary, reduction, calc_gradients)
