@@ -434,7 +434,7 @@ def rnnt_loss_pruned(logits, symbols, ranges, termination_symbol, boundary=None,
 
 
 def rnnt_loss_pruned_grad(logits, symbols, ranges, termination_symbol, boundary, rnnt_type="regular",
-                          delay_penalty=0.0, reduction="mean"):
+                          delay_penalty=0.0, reduction="mean", dtype=np.float32):
     """d rnnt_loss_pruned / d logits as TF autodiff produces it: the custom-op gradient
     (__init__.py:154-162: ans_grad * px_grad / py_grad) chained through get_rnnt_logprobs_pruned
     (gather of the band, minus logsumexp).  Returns (loss, grad [B,T,r,C])."""
@@ -443,8 +443,10 @@ def rnnt_loss_pruned_grad(logits, symbols, ranges, termination_symbol, boundary,
     S = symbols.shape[1]
     px, py = get_rnnt_logprobs_pruned(logits, symbols, ranges, termination_symbol, boundary, rnnt_type)
     px = _delay_penalty(px, boundary, rnnt_type, delay_penalty)
-    ans, (px_grad, py_grad) = mutual_information_recursion(px, py, boundary, True)
-    loss = _reduce(ans, reduction)
+    # dtype=float64 runs the recursion (the long dependent chain) in double: the "exact" comparison point
+    ans, (px_grad, py_grad) = mutual_information_recursion(px, py, boundary, True, dtype)
+    loss = _reduce(ans.astype(F32), reduction)
+    px_grad = px_grad.astype(F32); py_grad = py_grad.astype(F32)
     scale = {"none": -1.0, "sum": -1.0, "mean": -1.0 / B}[reduction]   # d loss / d ans[b]
     # band gradients: px[b,s,t] came from logits[b,t,s-s0,:] for s0 <= s < s0+r (s < S, t < T)
     s0 = ranges[:, :, 0]

@@ -1,0 +1,76 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/ftr.h declares; entry points
+fail loudly (no CPU fallback) when there is no device."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ftr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ftr_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(ft):
+    names = _declared_symbols()
+    assert len(names) >= 14
+    handle = ctypes.CDLL(ft._lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/ftr.h but not exported by libftr_hip.so"
+    assert set(names) == set(ft._lib.EXPORTED_SYMBOLS), "python binding and header disagree"
+
+
+def test_version_and_names(ft):
+    L = ft._lib.lib()
+    assert L.ftr_abi_version() == 100
+    assert L.ftr_package_version() == b"1.2" and ft.__version__ == "1.2"
+    # the op surface of the reference package (tf_fast_rnnt/python/tf_fast_rnnt/__init__.py:24-33,42,151)
+    for name in ("do_rnnt_pruning", "get_rnnt_logprobs", "get_rnnt_logprobs_joint", "get_rnnt_logprobs_pruned",
+                 "get_rnnt_logprobs_smoothed", "get_rnnt_prune_ranges", "rnnt_loss", "rnnt_loss_pruned",
+                 "rnnt_loss_simple", "rnnt_loss_smoothed", "mutual_information_recursion", "cummin"):
+        assert callable(getattr(ft, name))
+    assert L.ftr_mutual_information_workspace_floats(2, 3, 4) == 2 * 4 * 5
+
+
+def test_signatures_match_reference_keywords(ft):
+    import inspect
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(ft.rnnt_loss_simple) == ["lm", "am", "symbols", "termination_symbol", "boundary", "rnnt_type",
+                                        "delay_penalty", "reduction", "calc_gradients"]           # rnnt_loss.py:226-236
+    assert sig(ft.rnnt_loss_pruned) == ["logits", "symbols", "ranges", "termination_symbol", "boundary", "rnnt_type",
+                                        "delay_penalty", "reduction", "calc_gradients"]           # rnnt_loss.py:1023-1033
+    assert sig(ft.rnnt_loss_smoothed)[:11] == ["lm", "am", "symbols", "termination_symbol", "lm_only_scale",
+                                               "am_only_scale", "boundary", "rnnt_type", "delay_penalty", "reduction",
+                                               "calc_gradients"]                                  # rnnt_loss.py:1370-1382
+    assert sig(ft.get_rnnt_prune_ranges) == ["px_grad", "py_grad", "boundary", "s_range"]          # rnnt_loss.py:648-653
+    assert sig(ft.do_rnnt_pruning) == ["am", "lm", "ranges"]                                       # rnnt_loss.py:764-766
+    assert sig(ft.mutual_information_recursion) == ["px", "py", "boundary", "calc_gradients"]      # __init__.py:42-47
+    assert inspect.signature(ft.rnnt_loss_smoothed).parameters["lm_only_scale"].default == 0.1
+    assert inspect.signature(ft.rnnt_loss_simple).parameters["reduction"].default == "mean"
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")
+def test_no_cpu_fallback(ft):
+    L = ft._lib.lib()
+    buf = (ctypes.c_int32 * 8)()
+    addr = ctypes.addressof(buf)
+    rc = L.ftr_cummin_i32(addr, addr, 2, 2, None)
+    assert rc == -3 and b"no usable HIP device" in L.ftr_last_error()        # FTR_ERR_NO_DEVICE
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ft.mutual_information_recursion(torch.zeros(1, 2, 4), torch.zeros(1, 3, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ft.cummin(torch.zeros(2, 2, dtype=torch.int32))
+
+
+def test_argument_validation_without_device(ft):
+    L = ft._lib.lib()
+    assert L.ftr_cummin_i32(None, None, -1, 2, None) == 0 and b"negative" in L.ftr_last_error()   # FTR_ERR_INVALID_ARG
+    r = ctypes.c_int(0)
+    assert L.ftr_prune_ranges_i32(None, None, None, None, None, 0, 10, 20, 21, 50, ctypes.byref(r), None) == 1
+    assert r.value == 11                                       # s_range > S  ->  S + 1  (rnnt_loss.py:710-711)
+    assert L.ftr_prune_ranges_i32(None, None, None, None, None, 0, 10, 20, 25, 5, None, None) == 0

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import max_rel, reference_test_recipe, synthetic
+from helpers import assert_parity, max_rel, reference_test_recipe, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -143,7 +143,9 @@ def test_reference_scenario(ft, dev, oracle, cfg):
             o_pl, o_g = oracle.rnnt_loss_pruned_grad(lg.detach().cpu().numpy(), d["symbols"], ranges, blank, d["boundary"],
                                                      delay_penalty=0.2, reduction=reduction)
             np.testing.assert_allclose(pl.item(), o_pl, rtol=1e-4)
-            assert max_rel(lg.grad.cpu().numpy(), o_g) <= 1e-4, (r, reduction, max_rel(lg.grad.cpu().numpy(), o_g))
+            _, o_g64 = oracle.rnnt_loss_pruned_grad(lg.detach().cpu().numpy(), d["symbols"], ranges, blank, d["boundary"],
+                                                    delay_penalty=0.2, reduction=reduction, dtype=np.float64)
+            assert_parity(lg.grad.cpu().numpy(), o_g, o_g64, what=f"pruned grad r={r} {reduction}")
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
@@ -191,4 +193,4 @@ def test_full_size_pruned_step_properties(ft, dev):
     np.testing.assert_allclose(pyg.sum(dim=1).cpu().numpy(), 1.0, rtol=1e-4)
     g = out["logits_grad"]
     assert torch.isfinite(g).all() and torch.isfinite(out["pruned_loss"]).all()
-    np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=1e-6)
+    np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=1e-5)

@@ -1,0 +1,154 @@
+"""Host-side logic of the package on CPU tensors (no GPU, no native call): the torch restatements of the
+px/py builders, the penalty block, reductions and the batch-sharding helpers, each against the oracle;
+plus a world_size-2 gloo run of the collectives used by the sharded loss."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import reference_test_recipe, synthetic
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
+def test_get_rnnt_logprobs(ft, oracle, rnnt_type):
+    d = synthetic(0, 3, 11, 6, 9, ragged=True)
+    px, py = ft.get_rnnt_logprobs(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"], rnnt_type, _t(d["boundary"]))
+    o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], d["termination_symbol"], rnnt_type, d["boundary"])
+    assert np.array_equal(np.isneginf(px.numpy()), np.isneginf(o_px))
+    fin = np.isfinite(o_px)
+    np.testing.assert_allclose(px.numpy()[fin], o_px[fin], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(py.numpy(), o_py, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
+@pytest.mark.parametrize("scales", [(0.1, 0.2), (0.0, 0.0), (0.25, 0.0)])
+def test_get_rnnt_logprobs_smoothed(ft, oracle, rnnt_type, scales):
+    d = reference_test_recipe(1234, 2, 10, 7, 4)
+    px, py = ft.get_rnnt_logprobs_smoothed(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"],
+                                           scales[0], scales[1], _t(d["boundary"]), rnnt_type)
+    o_px, o_py = oracle.get_rnnt_logprobs_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"],
+                                                   scales[0], scales[1], d["boundary"], rnnt_type)
+    assert np.array_equal(np.isneginf(px.numpy()), np.isneginf(o_px))
+    fin = np.isfinite(o_px)
+    np.testing.assert_allclose(px.numpy()[fin], o_px[fin], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(py.numpy(), o_py, rtol=2e-5, atol=2e-5)
+
+
+def test_get_rnnt_logprobs_joint(ft, oracle):
+    d = synthetic(1, 2, 7, 4, 6, ragged=True)
+    logits = (d["am"][:, :, None, :] + d["lm"][:, None, :, :]).astype(np.float32)
+    for rnnt_type in ("regular", "modified", "constrained"):
+        px, py = ft.get_rnnt_logprobs_joint(_t(logits), _t(d["symbols"]), d["termination_symbol"], _t(d["boundary"]), rnnt_type)
+        o_px, o_py = oracle.get_rnnt_logprobs_joint(logits, d["symbols"], d["termination_symbol"], d["boundary"], rnnt_type)
+        fin = np.isfinite(o_px)
+        assert np.array_equal(np.isfinite(px.numpy()), fin)
+        np.testing.assert_allclose(px.numpy()[fin], o_px[fin], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(py.numpy(), o_py, rtol=1e-5, atol=1e-5)
+
+
+def test_fix_for_boundary_and_penalty(ft, oracle):
+    from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty, _reduce, _roll_by_shifts, fix_for_boundary
+    rng = np.random.default_rng(0)
+    px = rng.standard_normal((3, 4, 9)).astype(np.float32)
+    bd = np.array([[0, 0, 4, 8], [0, 0, 2, 5], [0, 0, 4, 1]], dtype=np.int32)
+    got = fix_for_boundary(_t(px), _t(bd)).numpy()
+    assert np.array_equal(got, oracle.fix_for_boundary(px, bd))
+    assert fix_for_boundary(_t(px), None) is not None
+    for rt in ("regular", "modified"):
+        got = _apply_delay_penalty(_t(px), _t(bd), rt, 0.3).numpy()
+        np.testing.assert_array_equal(got, oracle._delay_penalty(px, bd, rt, 0.3))
+        got = _apply_delay_penalty(_t(px), None, rt, 0.3).numpy()
+        np.testing.assert_array_equal(got, oracle._delay_penalty(px, None, rt, 0.3))
+    assert _apply_delay_penalty(_t(px), None, "regular", 0.0) is not None
+    # _roll_by_shifts docstring vector (rnnt_loss.py:823-834)
+    src = torch.arange(15).reshape(1, 3, 5)
+    want = torch.tensor([[[4, 0, 1, 2, 3], [8, 9, 5, 6, 7], [12, 13, 14, 10, 11]]])
+    assert torch.equal(_roll_by_shifts(src, torch.tensor([[1, 2, 3]])), want)
+    x = torch.tensor([1.0, 2.0, 4.0])
+    assert torch.equal(_reduce(x, "none"), -x) and _reduce(x, "sum").item() == -7.0
+    np.testing.assert_allclose(_reduce(x, "mean").item(), -7.0 / 3, rtol=1e-6)
+    with pytest.raises(ValueError):
+        _reduce(x, "avg")
+
+
+def test_shard_batch(ft):
+    from tf_fast_rnnt.distributed import shard_batch
+    for B in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            parts = [shard_batch(B, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == B
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _gloo_worker(rank, world, port, B, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tf-fast-rnnt_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tf_fast_rnnt.distributed import all_reduce_sum_differentiable, reduce_loss, shard_batch
+    from tf_fast_rnnt.rnnt_loss import get_rnnt_logprobs_smoothed
+    torch.manual_seed(0)
+    full = torch.randn(B, dtype=torch.float64)            # per-utterance losses of the whole batch
+    lo, hi = shard_batch(B, rank, world)
+    local = full[lo:hi].clone().requires_grad_(True)
+    out = {}
+    for red in ("mean", "sum"):
+        local.grad = None
+        v = reduce_loss(local, red)
+        v.backward()
+        out[red] = (v.item(), local.grad.clone())
+    # differentiable all-reduce: y = sum_r x_r ; d(sum(y*w))/dx_r = world * w  (every rank's y depends on x_r)
+    x = torch.full((3,), float(rank + 1), requires_grad=True)
+    y = all_reduce_sum_differentiable(x)
+    (y * torch.tensor([1.0, 2.0, 3.0])).sum().backward()
+    # sharded smoothed builder: global unigram through the process group == single-process full batch
+    g = torch.Generator().manual_seed(5)
+    Bf, T, S, C = 4, 6, 3, 5
+    am = torch.randn((Bf, T, C), generator=g); lm = torch.randn((Bf, S + 1, C), generator=g)
+    sym = torch.randint(0, C - 1, (Bf, S), generator=g)
+    l2, h2 = shard_batch(Bf, rank, world)
+    px_s, py_s = get_rnnt_logprobs_smoothed(lm[l2:h2], am[l2:h2], sym[l2:h2], C - 1, 0.1, 0.2, None, "regular",
+                                            process_group=dist.group.WORLD)
+    px_f, py_f = get_rnnt_logprobs_smoothed(lm, am, sym, C - 1, 0.1, 0.2, None, "regular")
+    ok_smoothed = torch.allclose(py_s, py_f[l2:h2], rtol=1e-5, atol=1e-6) and \
+        torch.allclose(px_s[:, :, :T], px_f[l2:h2, :, :T], rtol=1e-5, atol=1e-6)
+    q.put((rank, out["mean"][0], out["sum"][0], out["mean"][1].tolist(), y.detach().tolist(), x.grad.tolist(),
+           full.mean().item(), full.sum().item(), bool(ok_smoothed)))
+    dist.destroy_process_group()
+
+
+def test_sharded_loss_gloo_world2():
+    """N>1 path on CPU: batch sharded over 2 ranks, one small all-reduce, result == unsharded reduction."""
+    world, B = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, mean_v, sum_v, mean_grad, y, xg, full_mean, full_sum, ok_smoothed in res:
+        np.testing.assert_allclose(mean_v, full_mean, rtol=1e-12)
+        np.testing.assert_allclose(sum_v, full_sum, rtol=1e-12)
+        np.testing.assert_allclose(mean_grad, 1.0 / B, rtol=1e-12)      # d mean / d loss_b = 1/B on every shard
+        assert y == [3.0, 3.0, 3.0]
+        assert xg == [2.0, 4.0, 6.0]
+        assert ok_smoothed

@@ -50,11 +50,17 @@ def shard_batch(B: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 def reduce_loss(local_loss_none: torch.Tensor, reduction: str = "mean", group=None) -> torch.Tensor:
     """Combine per-utterance losses (reduction="none" output of any loss driver, this rank's shard) into
-    the value the single-device call would return for the whole batch.  Differentiable; exactly one
-    all-reduce of 2 floats."""
+    the value the single-device call would return for the whole batch: exactly one all-reduce of 2 floats.
+
+    The returned scalar has the global VALUE on every rank and the LOCAL gradient: d/d(loss of a local
+    utterance) is 1 ("sum") or 1/global_count ("mean"), so that after every rank calls backward() and the
+    caller's data-parallel gradient all-reduce sums parameter gradients over ranks, the result equals the
+    single-device gradient (the replicated scalar is not counted world_size times)."""
     if reduction not in ("mean", "sum"):
         raise ValueError("reduce_loss supports 'mean' and 'sum'")
-    packed = torch.stack((local_loss_none.sum(), local_loss_none.new_tensor(float(local_loss_none.numel()))))
+    local_sum = local_loss_none.sum()
+    packed = torch.stack((local_sum.detach(), local_sum.new_tensor(float(local_loss_none.numel()))))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        packed = all_reduce_sum_differentiable(packed, group)
-    return packed[0] if reduction == "sum" else packed[0] / packed[1]
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    total = local_sum + (packed[0] - local_sum.detach())      # global value, local gradient
+    return total if reduction == "sum" else total / packed[1]
