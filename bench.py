@@ -133,10 +133,10 @@ def algorithmic_bytes(B, T, S, C, r):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(B, T, S, C, r, sample_B=16, seed=0):
-    """The oracle (CPU port of the same path) timed on this host, 1 thread, on `sample_B` utterances of the
-    same workload: px/py builder + recursion fwd+bwd + ranges + gather + sigmoid + pruned log-probs +
-    recursion fwd+bwd + gradient w.r.t. logits."""
+def cpu_baseline(B, T, S, C, r, sample_B=8, seed=0, min_seconds=12.0):
+    """The oracle (CPU port of the same path) timed on this host, 1 thread, on batches of `sample_B`
+    utterances of the same workload repeated until >= `min_seconds` of CPU work: px/py builder + recursion
+    fwd+bwd + ranges + gather + sigmoid + pruned log-probs + recursion fwd+bwd + gradient w.r.t. logits."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rnnt_oracle as O
     try:
@@ -151,17 +151,23 @@ def cpu_baseline(B, T, S, C, r, sample_B=16, seed=0):
     sym = rng.integers(0, C - 1, (sample_B, S)).astype(np.int32)
     bd = np.zeros((sample_B, 4), np.int32); bd[:, 2] = S; bd[:, 3] = T
     os.environ["OMP_NUM_THREADS"] = "1"
+    done = 0
     with limiter:
         t0 = time.perf_counter()
-        _, (gx, gy) = O.rnnt_loss_simple(lm, am, sym, C - 1, bd, reduction="sum", calc_gradients=True)
-        ranges = O.get_rnnt_prune_ranges(gx, gy, bd, r)
-        am_p, lm_p = O.do_rnnt_pruning(am, lm, ranges)
-        logits = (1.0 / (1.0 + np.exp(-(am_p + lm_p)))).astype(np.float32)
-        O.rnnt_loss_pruned_grad(logits, sym, ranges, C - 1, bd, reduction="sum")
-        dt = time.perf_counter() - t0
-    return dict(value=sample_B / dt, unit="utterances/s", cores=1, kind="port",
-                sample=f"{sample_B} of {B} utterances of the same workload (oracle/ C + numpy, single thread, "
-                       f"{dt:.1f} s of CPU work; loss pipeline without the torch-autograd tail to am/lm)")
+        while True:
+            _, (gx, gy) = O.rnnt_loss_simple(lm, am, sym, C - 1, bd, reduction="sum", calc_gradients=True)
+            ranges = O.get_rnnt_prune_ranges(gx, gy, bd, r)
+            am_p, lm_p = O.do_rnnt_pruning(am, lm, ranges)
+            logits = (1.0 / (1.0 + np.exp(-(am_p + lm_p)))).astype(np.float32)
+            O.rnnt_loss_pruned_grad(logits, sym, ranges, C - 1, bd, reduction="sum")
+            done += sample_B
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds or done >= 4096:
+                break
+    return dict(value=round(done / dt, 3), unit="utterances/s", cores=1, kind="port",
+                sample=f"{done} utterances of the same workload in batches of {sample_B} (oracle/: C recursion + numpy "
+                       f"builders, single thread, {dt:.1f} s of CPU work; loss pipeline forward + gradients w.r.t. "
+                       f"px/py and pruned logits, without the autograd tail to am/lm)")
 
 
 # ------------------------------------------------------------------------------------------------ main

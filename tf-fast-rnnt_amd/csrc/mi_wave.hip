@@ -57,8 +57,10 @@ __device__ __forceinline__ float dpp_wave_shr1(float old_for_lane0, float src) {
 // one barrier before it is read and is overwritten (64 steps later) at least two barriers after it
 // was read -- for STG = 5 (regular), 1 (modified); the arithmetic is in DESIGN.md "ring schedule".
 
-template <bool MOD>
-__global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
+// MAXW = maximum waves per workgroup of this instantiation: the launch bound 64*MAXW is what sizes the
+// register budget (512 / 256 / 128 VGPRs per lane for MAXW = 4 / 8 / 16).
+template <bool MOD, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void mi_wave_fwd_kernel(
     const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
     float* __restrict__ ws, float* __restrict__ ans, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,11 +134,6 @@ __global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
             for (int e = 0; e < 4; ++e)
               if (c0 + e >= 1 && c0 + e < Tn) vy[e] = pyb[base + e];
           }
-          if (r == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c0 + e == 0) vy[e] = 0.0f;  // origin cell: b = pcur(0) + 0
-          }
         }
       }
       x[m] = vx;
@@ -144,7 +141,10 @@ __global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
     }
   };
 
-  auto write_tile = [&](const f4 (&x)[4], const f4 (&y)[4]) {
+  // kk = chunk being parked.  The origin cell (row s_begin, column t_begin: chunk 0, tile row 0, quad 0,
+  // element 0 of wave 0) gets Y := 0 so that p = logadd(-inf, pcur(0) + 0) = 0 falls out of the recursion.
+  // (Patched here, after the loads have landed anyway, never right behind the load issue.)
+  auto write_tile = [&](int kk, const f4 (&x)[4], const f4 (&y)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = 16 * m + frow;
@@ -154,24 +154,36 @@ __global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
         xs[e] = fmaxf(x[m][e] * kLog2e, kNeg);  // log2 domain; -inf (and nan) -> kNeg
         ys[e] = fmaxf(y[m][e] * kLog2e, kNeg);
       }
+      if (m == 0 && kk == 0 && w == 0 && lane == 0) ys[0] = 0.0f;
       tX[fq * PLANE + row] = xs;
       tY[fq * PLANE + row] = ys;
     }
   };
 
+  // Lane 0 has no left neighbour in the wave: its "up" value comes from the ring.  It is folded into X
+  // (off the dependent chain) so the DPP shift can run with bound_ctrl (lane 0 reads 0) and fuse into
+  // the add: a = v_add_f32_dpp(X', pcur).
+  const float lane0 = (lane == 0) ? 1.0f : 0.0f;
   auto compute_chunk = [&](int k) {
+    f4 Xn = tX[lane], Yn = tY[lane];
+    f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int j0 = CH * k + 4 * q;
-      const f4 X4 = tX[q * PLANE + lane];
-      const f4 Y4 = tY[q * PLANE + lane];
-      const f4 E4 = ring_in[(j0 & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
+      const f4 X4 = Xn, Y4 = Yn, E4 = En;
+      if (q + 1 < NQ) {  // next quad's operands are fetched while this quad's chain runs
+        Xn = tX[(q + 1) * PLANE + lane];
+        Yn = tY[(q + 1) * PLANE + lane];
+        En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
+      }
+      f4 XE;  // X + (lane 0 ? value from the wave above : 0)
+      XE[0] = X4[0] + lane0 * ecarry; XE[1] = X4[1] + lane0 * E4[0];
+      XE[2] = X4[2] + lane0 * E4[1];  XE[3] = X4[3] + lane0 * E4[2];
       f4 G4, P4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float ev = (e == 0) ? ecarry : E4[e - 1];
-        const float up = dpp_wave_shr1(ev, pcur);
-        const float a = up + X4[e];
+        const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pcur), 0x138, 0xf, 0xf, true));
+        const float a = up + XE[e];
         const float c = pcur + Y4[e];
         const float d = a - c;
         const float mx = fmaxf(a, c);
@@ -193,14 +205,18 @@ __global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
     }
   };
 
-  auto store_G = [&](int k) {
+  auto fetch_G = [&](f4 (&gq)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gq[m] = tX[fq * PLANE + 16 * m + frow];
+  };
+  auto store_G = [&](int k, const f4 (&gq)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = 16 * m + frow;
       const int r = row0 + row;
       if (r < Sn) {
         const int c0 = CH * k + 4 * fq - SKEW * row;
-        const f4 g = tX[fq * PLANE + row];
+        const f4 g = gq[m];
         const ptrdiff_t base = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
         if (c0 >= 0 && c0 + 3 < Tn) {
           *reinterpret_cast<f4u*>(wsb + base) = g;
@@ -217,12 +233,17 @@ __global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int k = g + u - STG * w;
-      if (k >= 0 && k < nchunks) {
+      const bool active = (k >= 0 && k < nchunks);
+      f4 gq[4];
+      if (active) {
         if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
         compute_chunk(k);
-        store_G(k);
+        fetch_G(gq);  // G quads out of the tile before it is refilled
       }
-      if (k + 1 >= 0 && k + 1 < nchunks) write_tile(rx[u], ry[u]);
+      // order matters for the vmcnt wait in front of write_tile: park the next chunk first (waits for
+      // loads issued >= 1 slot ago), only then issue this chunk's stores and the next prefetch.
+      if (k + 1 >= 0 && k + 1 < nchunks) write_tile(k + 1, rx[u], ry[u]);
+      if (active) store_G(k, gq);
       if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, rx[u], ry[u]);
       __syncthreads();
     }
@@ -230,8 +251,8 @@ __global__ __launch_bounds__(1024) void mi_wave_fwd_kernel(
 }
 
 // Backward on reversed coordinates: row index r = s_end - s (lane), column c = t_end - t.
-template <bool MOD>
-__global__ __launch_bounds__(1024) void mi_wave_bwd_kernel(
+template <bool MOD, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void mi_wave_bwd_kernel(
     const int32_t* __restrict__ boundary, const float* __restrict__ ws, float* __restrict__ px_grad,
     float* __restrict__ py_grad, float* __restrict__ ans_grad, int overwrite, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -360,7 +381,11 @@ __global__ __launch_bounds__(1024) void mi_wave_bwd_kernel(
     }
   };
 
-  auto store_out = [&](int k) {
+  auto fetch_out = [&](f4 (&oq)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) oq[m] = tG[fq * PLANE + 16 * m + frow];
+  };
+  auto store_out = [&](int k, const f4 (&oq)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = 16 * m + frow;
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(1024) void mi_wave_bwd_kernel(
       if (r < Sn) {
         const int c0 = CH * k + 4 * fq - SKEW * row;
         const int s = bd.se - r;
-        const f4 gx = tG[fq * PLANE + row];
+        const f4 gx = oq[m];
         const f4 gy = tO[fq * PLANE + row];
         if (r >= 1) {  // px_grad rows are s < se; columns c in [NOFF, Tn)
           const ptrdiff_t lo = (ptrdiff_t)s * T1 + bd.te - c0 - 3;
@@ -400,12 +425,15 @@ __global__ __launch_bounds__(1024) void mi_wave_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int k = g + u - STG * w;
-      if (k >= 0 && k < nchunks) {
+      const bool active = (k >= 0 && k < nchunks);
+      f4 oq[4];
+      if (active) {
         if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
         compute_chunk(k);
-        store_out(k);
+        fetch_out(oq);  // px_grad quads out of the G tile before it is refilled
       }
       if (k + 1 >= 0 && k + 1 < nchunks) write_tile(rg[u]);
+      if (active) store_out(k, oq);
       if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, rg[u]);
       __syncthreads();
     }
@@ -429,6 +457,25 @@ int prepare_lds(K kernel, size_t lds, const char* what) {
   return FTR_OK;
 }
 
+template <bool MOD, int MAXW>
+int launch_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B,
+               int S, int T, int NW, hipStream_t st) {
+  const size_t lds = wave_lds_bytes(NW);
+  int rc = prepare_lds(mi_wave_fwd_kernel<MOD, MAXW>, lds, "mi_wave_fwd");
+  if (rc != FTR_OK) return rc;
+  hipLaunchKernelGGL((mi_wave_fwd_kernel<MOD, MAXW>), dim3(B), dim3(64 * NW), lds, st, px, py, boundary, ws, ans, S, T);
+  return check_launch("mi_wave_fwd");
+}
+template <bool MOD, int MAXW>
+int launch_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad,
+               int overwrite, int B, int S, int T, int NW, hipStream_t st) {
+  const size_t lds = wave_lds_bytes(NW);
+  int rc = prepare_lds(mi_wave_bwd_kernel<MOD, MAXW>, lds, "mi_wave_bwd");
+  if (rc != FTR_OK) return rc;
+  hipLaunchKernelGGL((mi_wave_bwd_kernel<MOD, MAXW>), dim3(B), dim3(64 * NW), lds, st, boundary, ws, px_grad, py_grad, ans_grad, overwrite, S, T);
+  return check_launch("mi_wave_bwd");
+}
+
 }  // namespace
 
 int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans,
@@ -438,16 +485,12 @@ int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float
     set_error("mi_wave_fwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
     return FTR_ERR_UNSUPPORTED;
   }
-  const size_t lds = wave_lds_bytes(NW);
-  int rc;
-  if (modified) {
-    if ((rc = prepare_lds(mi_wave_fwd_kernel<true>, lds, "mi_wave_fwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(mi_wave_fwd_kernel<true>, dim3(B), dim3(64 * NW), lds, st, px, py, boundary, ws, ans, S, T);
-  } else {
-    if ((rc = prepare_lds(mi_wave_fwd_kernel<false>, lds, "mi_wave_fwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(mi_wave_fwd_kernel<false>, dim3(B), dim3(64 * NW), lds, st, px, py, boundary, ws, ans, S, T);
-  }
-  return check_launch("mi_wave_fwd");
+#define FTR_DISPATCH(MODV)                                                                      \
+  (NW <= 4 ? launch_fwd<MODV, 4>(px, py, boundary, ws, ans, B, S, T, NW, st)                   \
+           : NW <= 8 ? launch_fwd<MODV, 8>(px, py, boundary, ws, ans, B, S, T, NW, st)         \
+                     : launch_fwd<MODV, 16>(px, py, boundary, ws, ans, B, S, T, NW, st))
+  return modified ? FTR_DISPATCH(true) : FTR_DISPATCH(false);
+#undef FTR_DISPATCH
 }
 
 int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad,
@@ -457,17 +500,15 @@ int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float*
     set_error("mi_wave_bwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
     return FTR_ERR_UNSUPPORTED;
   }
-  const size_t lds = wave_lds_bytes(NW);
-  int rc;
-  if (modified) {
-    if ((rc = prepare_lds(mi_wave_bwd_kernel<true>, lds, "mi_wave_bwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(mi_wave_bwd_kernel<true>, dim3(B), dim3(64 * NW), lds, st, boundary, ws, px_grad, py_grad, ans_grad, overwrite, S, T);
-  } else {
-    if ((rc = prepare_lds(mi_wave_bwd_kernel<false>, lds, "mi_wave_bwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(mi_wave_bwd_kernel<false>, dim3(B), dim3(64 * NW), lds, st, boundary, ws, px_grad, py_grad, ans_grad, overwrite, S, T);
-  }
-  return check_launch("mi_wave_bwd");
+#define FTR_DISPATCH(MODV)                                                                                              \
+  (NW <= 4 ? launch_bwd<MODV, 4>(boundary, ws, px_grad, py_grad, ans_grad, overwrite, B, S, T, NW, st)                 \
+           : NW <= 8 ? launch_bwd<MODV, 8>(boundary, ws, px_grad, py_grad, ans_grad, overwrite, B, S, T, NW, st)       \
+                     : launch_bwd<MODV, 16>(boundary, ws, px_grad, py_grad, ans_grad, overwrite, B, S, T, NW, st))
+  return modified ? FTR_DISPATCH(true) : FTR_DISPATCH(false);
+#undef FTR_DISPATCH
 }
+
+namespace {
 
 // ---------------------------------------------------------------------------------------------
 // Hardware self-test: the wavefront kernels rely on (1) wave_shr:1 DPP shifting across all 64 lanes
@@ -487,6 +528,8 @@ __global__ void selftest_kernel(const float* __restrict__ in, float* __restrict_
   if (lane == 0) result[0] = (m == ~0ull) ? 1 : 0;
 }
 
+}  // namespace
+
 int selftest(hipStream_t st, int* result_dev) {
   // scratch lives behind result_dev: [0] result int, then 512 floats in, 512 floats out
   float* in = reinterpret_cast<float*>(result_dev + 4);
@@ -496,7 +539,9 @@ int selftest(hipStream_t st, int* result_dev) {
   if (hipMemcpyAsync(in, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) {
     set_error("selftest: memcpy failed"); return FTR_ERR_LAUNCH;
   }
-  hipStreamSynchronize(st);  // host[] is on the stack
+  if (hipStreamSynchronize(st) != hipSuccess) {  // host[] is on the stack
+    set_error("selftest: sync failed"); return FTR_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, in, out, result_dev);
   return check_launch("selftest");
 }
