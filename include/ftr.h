@@ -137,6 +137,12 @@ int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, con
  * stream has drained, ((int*)scratch_dev)[0] == 1 means pass. */
 int ftr_selftest(void* scratch_dev, void* stream);
 
+/* Diagnostic: copies 16 counters out of the library (host pointer).  All zero unless the library was built
+ * with `make STAMPS=1`, in which case they are per-segment s_memtime sums of the wavefront kernels'
+ * steady-state slot ([0..5] forward, [8..13] backward: compute, refill tile, issue stores, issue loads,
+ * barrier, slots counted).  Synchronises the device. */
+int ftr_debug_stamps(unsigned long long* out16);
+
 #ifdef __cplusplus
 }
 #endif

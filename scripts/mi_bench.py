@@ -1,0 +1,61 @@
+"""Times the native mutual-information forward / backward alone (HIP events on the launch stream) over a few
+lattice shapes.  Diagnostic helper for kernel tuning: python scripts/mi_bench.py [B S T ...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tf-fast-rnnt_amd"))
+import torch
+import tf_fast_rnnt as ft
+from tf_fast_rnnt import _lib
+from tf_fast_rnnt.mutual_information import _ptr
+
+def run(B, S, T, iters=20, impl=0, cold=False):
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    L.ftr_set_mi_impl(impl)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    px = (torch.randn((B, S, T + 1), generator=g) - 6.0).to(dev)
+    py = (torch.randn((B, S + 1, T), generator=g) - 6.0).to(dev)
+    bd = torch.zeros((B, 4), dtype=torch.int32); bd[:, 2] = S; bd[:, 3] = T
+    px[:, :, T] = float("-inf")
+    bd = bd.to(dev)
+    ws = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=dev)
+    pg = torch.empty_like(ws) if impl == 1 else None
+    ans = torch.empty(B, device=dev); ag = torch.ones(B, device=dev)
+    gx = torch.empty_like(px); gy = torch.empty_like(py)
+    st = torch.cuda.current_stream().cuda_stream
+    flush = torch.empty(512 * 1024 * 1024 // 4, device=dev) if cold else None
+    tf = tb = 0.0
+    for i in range(iters + 3):
+        if cold: flush.fill_(1.0)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        _lib.call("ftr_mutual_information_fwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(ans), B, S, T, 0, st)
+        e[1].record()
+        _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(pg), _ptr(gx), _ptr(gy), _ptr(ag), 1, B, S, T, 0, st)
+        e[2].record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
+    L.ftr_set_mi_impl(0)
+    cells = B * (S + 1) * (T + 1)
+    return 1e3 * tf / iters, 1e3 * tb / iters, cells
+
+if __name__ == "__main__":
+    shapes = [(32, 200, 1000), (32, 63, 1000), (32, 127, 1000), (8, 200, 1000), (64, 200, 1000), (256, 200, 1000), (32, 100, 512), (32, 300, 2000), (8, 1000, 8000)]
+    if len(sys.argv) > 3:
+        shapes = [tuple(int(v) for v in sys.argv[1:4])]
+    for cold in (False, True):
+        for (B, S, T) in shapes:
+            f, b, cells = run(B, S, T, cold=cold)
+            nslots = ((T + 1 + 63 + 15) // 16) + 5 * ((S + 1 + 63) // 64 - 1)
+            print(f"B={B:4d} S={S:5d} T={T:5d} {'cold' if cold else 'warm'}: fwd {f:8.1f} us ({12*cells/f/1e3:7.1f} GB/s alg, {f/nslots*1e3:6.0f} ns/slot)   bwd {b:8.1f} us ({20*cells/b/1e3:7.1f} GB/s alg, {b/nslots*1e3:6.0f} ns/slot)", flush=True)
+    f, b, cells = run(32, 200, 1000, impl=1)
+    print(f"plain family B=32 S=200 T=1000: fwd {f:.1f} us  bwd {b:.1f} us")
+    import ctypes
+    buf = (ctypes.c_ulonglong * 16)()
+    _lib.lib().ftr_debug_stamps(buf)
+    v = list(buf)
+    if any(v):
+        for name, o in (("fwd", 0), ("bwd", 8)):
+            n = max(v[o + 5], 1)
+            print(name, "per-slot cycles: compute %.0f  refill %.0f  stores %.0f  loads %.0f  barrier %.0f  (slots %d)" % tuple([v[o + i] / n for i in range(5)] + [n]))

@@ -173,4 +173,12 @@ int ftr_selftest(void* scratch_dev, void* stream) {
   return selftest(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<int*>(scratch_dev));
 }
 
+int ftr_debug_stamps(unsigned long long* out16) {
+  clear_error();
+  FTR_REQUIRE(out16, "debug_stamps: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return debug_stamps(out16);
+}
+
 }  // extern "C"

@@ -40,8 +40,25 @@ constexpr int CH = 16;              // steps per chunk
 constexpr int NQ = CH / 4;          // quads (4 consecutive steps) per chunk
 constexpr int PLANE = 66;           // float4 per [quad] plane: 64 rows + 2 pad (conflict-free fill+read)
 constexpr int TILE_F4 = NQ * PLANE; // one tile = 264 float4 = 4224 B
-constexpr int NPF = 2;              // chunks in flight in registers (prefetch distance)
+// chunks in flight in registers (prefetch distance): 3 where the register budget allows (<= 8 waves per
+// workgroup), 2 for 16-wave workgroups (128 VGPRs per lane, and 4 waves per SIMD hide latency themselves)
+template <int MAXW> struct Prefetch { static constexpr int N = (MAXW <= 8) ? 3 : 2; };
+constexpr int kVmcnt0 = 0x0F70;     // s_waitcnt immediate: vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
 constexpr int RINGN = 64;
+
+// Diagnostic build only (make STAMPS=1): per-segment s_memtime sums of the steady-state slot of wave 0 of
+// workgroup 0, read back through ftr_debug_stamps().  Never compiled into the product library.
+__device__ unsigned long long g_stamps[16];
+#ifdef FTR_STAMPS
+#define FTR_STAMP(var)                                                                            \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                   \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+#else
+#define FTR_STAMP(var) do { } while (0)
+#endif
 
 __device__ __forceinline__ float dpp_wave_shr1(float old_for_lane0, float src) {
   // lane l (l >= 1) receives src of lane l-1; lane 0 keeps `old_for_lane0` (bound_ctrl = 0).
@@ -66,6 +83,7 @@ __global__ __launch_bounds__(64 * MAXW) void mi_wave_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int STG = MOD ? 1 : 5;
+  constexpr int NPF = Prefetch<MAXW>::N;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,25 +247,108 @@ __global__ __launch_bounds__(64 * MAXW) void mi_wave_fwd_kernel(
     }
   };
 
-  for (int g = -(NPF + 1); g < Gtot; g += NPF) {
+  // ---- interior ("fast") chunks: every quad of every lane-row lies inside [1, Tn) in columns, so loads and
+  // stores are plain 16-byte accesses with no per-element guards and no divergent control flow.  Rows
+  // beyond the utterance are clamped to a valid row: what they compute never reaches a valid row (data
+  // only moves from row s-1 to row s) and is never stored.
+  int offX[4], offY[4], offG[4];
+  bool rvalid[4];
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-      const int k = g + u - STG * w;
-      const bool active = (k >= 0 && k < nchunks);
-      f4 gq[4];
-      if (active) {
-        if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
-        compute_chunk(k);
-        fetch_G(gq);  // G quads out of the tile before it is refilled
-      }
-      // order matters for the vmcnt wait in front of write_tile: park the next chunk first (waits for
-      // loads issued >= 1 slot ago), only then issue this chunk's stores and the next prefetch.
-      if (k + 1 >= 0 && k + 1 < nchunks) write_tile(k + 1, rx[u], ry[u]);
-      if (active) store_G(k, gq);
-      if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, rx[u], ry[u]);
-      __syncthreads();
+  for (int m = 0; m < 4; ++m) {
+    const int row = 16 * m + frow;
+    const int r = row0 + row;
+    const int cq = 4 * fq - SKEW * row;
+    const int rxc = min(max(r - 1, 0), max(Sn - 2, 0));   // px row s-1 (clamped)
+    const int ryc = min(r, Sn - 1);                       // py row s   (clamped)
+    offX[m] = (bd.sb + rxc) * T1 + bd.tb + cq + (MOD ? -1 : 0);
+    offY[m] = (bd.sb + ryc) * T + bd.tb + cq - 1;
+    offG[m] = (bd.sb + r) * (T + 1) + bd.tb + cq;
+    rvalid[m] = r < Sn;
+  }
+  auto load_fast = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
+    const float* px_k = pxb + CH * k;   // wave-uniform part of the address
+    const float* py_k = pyb + CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      x[m] = *reinterpret_cast<const f4u*>(px_k + offX[m]);
+      y[m] = *reinterpret_cast<const f4u*>(py_k + offY[m]);
+    }
+  };
+  auto store_fast = [&](int k, const f4 (&gq)[4]) {
+    float* ws_k = wsb + CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (rvalid[m]) *reinterpret_cast<f4u*>(ws_k + offG[m]) = gq[m];
+  };
+
+  auto slot_general = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
+    const bool active = (k >= 0 && k < nchunks);
+    f4 gq[4];
+    if (active) {
+      if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
+      compute_chunk(k);
+      fetch_G(gq);  // G quads out of the tile before it is refilled
+    }
+    // park the next chunk first (its loads were issued NPF slots ago), only then issue this chunk's
+    // stores and the next prefetch
+    if (k + 1 >= 0 && k + 1 < nchunks) write_tile(k + 1, x, y);
+    if (active) store_G(k, gq);
+    if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, x, y);
+    __syncthreads();
+  };
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto slot_fast = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
+    f4 gq[4];
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    FTR_STAMP(t0);
+    compute_chunk(k);
+    FTR_STAMP(t1);
+    fetch_G(gq);
+    write_tile(k + 1, x, y);
+    FTR_STAMP(t2);
+    store_fast(k, gq);
+    FTR_STAMP(t3);
+    load_fast(k + 1 + NPF, x, y);
+    FTR_STAMP(t4);
+    __syncthreads();
+    FTR_STAMP(t5);
+    st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += t5 - t4; st_acc[5] += 1;
+  };
+
+  // Slot schedule.  Iteration `it` runs NPF slots; this wave's chunk in the first of them is
+  // k0 = NPF*it - (NPF+1) - STG*w.  Every wave runs exactly NIT iterations (one barrier per slot); each wave
+  // splits them into [general | fast | general] by its own k0.  Fast slot k: stores of k and loads of
+  // k+1+NPF are interior  <=>  K0 <= k and k+1+NPF < K1; k >= 1 keeps the origin special cases out.
+  const int K0 = MOD ? 1 : 4;                            // 16k - 63*SKEW >= 1
+  const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;    // 16k + 15 < Tn
+  const int KF0 = K0, KF1 = (Sn >= 2) ? K1 - 1 - NPF : 0;
+  const int NIT = (Gtot + NPF + 1 + NPF - 1) / NPF;
+  const int base = -(NPF + 1) - STG * w;                 // k0 = base + NPF*it
+  int it1 = (KF0 - base + NPF - 1) / NPF;                // first it with k0 >= KF0
+  int it2 = (KF1 - NPF + 1 - base + NPF - 1) / NPF;      // first it with k0 + NPF - 1 >= KF1
+  it1 = min(max(it1, 0), NIT);
+  it2 = min(max(it2, it1), NIT);
+
+  int it = 0;
+  for (; it < it1; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+  }
+  if (it < it2) {
+    __builtin_amdgcn_s_waitcnt(kVmcnt0);  // nothing pending when the steady-state loop is entered
+    for (; it < it2; ++it) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) slot_fast(base + NPF * it + u, rx[u], ry[u]);
     }
   }
+  for (; it < NIT; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+  }
+#ifdef FTR_STAMPS
+  if (b == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 6; ++i) g_stamps[i] = st_acc[i];
+#endif
 }
 
 // Backward on reversed coordinates: row index r = s_end - s (lane), column c = t_end - t.
@@ -259,6 +360,7 @@ __global__ __launch_bounds__(64 * MAXW) void mi_wave_bwd_kernel(
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int STG = MOD ? 1 : 5;
   constexpr int NOFF = MOD ? 1 : 0;
+  constexpr int NPF = Prefetch<MAXW>::N;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -351,11 +453,16 @@ __global__ __launch_bounds__(64 * MAXW) void mi_wave_bwd_kernel(
   };
 
   auto compute_chunk = [&](int k) {
+    f4 Gn = tG[lane];
+    f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int j0 = CH * k + 4 * q;
-      const f4 G4 = tG[q * PLANE + lane];
-      const f4 E4 = ring_in[(j0 & (RINGN - 1)) >> 2];
+      const f4 G4 = Gn, E4 = En;
+      if (q + 1 < NQ) {
+        Gn = tG[(q + 1) * PLANE + lane];
+        En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
+      }
       f4 XO4, PX4, PY4, PG4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -421,23 +528,112 @@ __global__ __launch_bounds__(64 * MAXW) void mi_wave_bwd_kernel(
     }
   };
 
-  for (int g = -(NPF + 1); g < Gtot; g += NPF) {
+  // ---- interior ("fast") chunks, see the forward kernel.  Clamped rows read some valid row's G: their
+  // flow is exactly zero (nothing flows past row s_begin: G[s_begin, t] == 0), so garbage G cannot matter.
+  int offG[4], offPX[4], offPY[4];
+  bool rvalid[4], xvalid[4];
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-      const int k = g + u - STG * w;
-      const bool active = (k >= 0 && k < nchunks);
-      f4 oq[4];
-      if (active) {
-        if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
-        compute_chunk(k);
-        fetch_out(oq);  // px_grad quads out of the G tile before it is refilled
+  for (int m = 0; m < 4; ++m) {
+    const int row = 16 * m + frow;
+    const int r = row0 + row;
+    const int cq = 4 * fq - SKEW * row;
+    const int rc = min(r, Sn - 1);
+    // element e of the quad is column c0+e (reversed): memory holds it at t = te - c0 - e; lowest address
+    // of the quad is e = 3
+    offG[m] = (bd.se - rc) * (T + 1) + bd.te - cq - 3;
+    offPX[m] = (bd.se - r) * T1 + bd.te - cq - 3;
+    offPY[m] = (bd.se - r) * T + bd.te - cq - 3;
+    rvalid[m] = r < Sn;
+    xvalid[m] = r >= 1 && r < Sn;
+  }
+  auto load_fast = [&](int k, f4 (&gq)[4]) {
+    const float* ws_k = wsb - CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f4 t4 = *reinterpret_cast<const f4u*>(ws_k + offG[m]);
+      gq[m][0] = t4[3]; gq[m][1] = t4[2]; gq[m][2] = t4[1]; gq[m][3] = t4[0];
+    }
+  };
+  auto store_fast = [&](int k, const f4 (&oq)[4]) {
+    float* px_k = pxg - CH * k;
+    float* py_k = pyg - CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f4 gy = tO[fq * PLANE + 16 * m + frow];
+      if (xvalid[m]) {
+        f4 o; o[0] = oq[m][3]; o[1] = oq[m][2]; o[2] = oq[m][1]; o[3] = oq[m][0];
+        *reinterpret_cast<f4u*>(px_k + offPX[m]) = o;
       }
-      if (k + 1 >= 0 && k + 1 < nchunks) write_tile(rg[u]);
-      if (active) store_out(k, oq);
-      if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, rg[u]);
-      __syncthreads();
+      if (rvalid[m]) {
+        f4 o; o[0] = gy[3]; o[1] = gy[2]; o[2] = gy[1]; o[3] = gy[0];
+        *reinterpret_cast<f4u*>(py_k + offPY[m]) = o;
+      }
+    }
+  };
+
+  auto slot_general = [&](int k, f4 (&gq)[4]) {
+    const bool active = (k >= 0 && k < nchunks);
+    f4 oq[4];
+    if (active) {
+      if (!MOD && k == 0) ecarry = rings[w * RINGN + 63];
+      compute_chunk(k);
+      fetch_out(oq);  // px_grad quads out of the G tile before it is refilled
+    }
+    if (k + 1 >= 0 && k + 1 < nchunks) write_tile(gq);
+    if (active) store_out(k, oq);
+    if (k + 1 + NPF >= 0 && k + 1 + NPF < nchunks) load_chunk(k + 1 + NPF, gq);
+    __syncthreads();
+  };
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto slot_fast = [&](int k, f4 (&gq)[4]) {
+    f4 oq[4];
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    FTR_STAMP(t0);
+    compute_chunk(k);
+    FTR_STAMP(t1);
+    fetch_out(oq);
+    write_tile(gq);
+    FTR_STAMP(t2);
+    store_fast(k, oq);
+    FTR_STAMP(t3);
+    load_fast(k + 1 + NPF, gq);
+    FTR_STAMP(t4);
+    __syncthreads();
+    FTR_STAMP(t5);
+    st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += t5 - t4; st_acc[5] += 1;
+  };
+
+  // slot schedule: identical to the forward kernel's (columns are reversed, the geometry is the same)
+  const int K0 = MOD ? 1 : 4;
+  const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;
+  const int KF0 = K0, KF1 = K1 - 1 - NPF;
+  const int NIT = (Gtot + NPF + 1 + NPF - 1) / NPF;
+  const int base = -(NPF + 1) - STG * w;
+  int it1 = (KF0 - base + NPF - 1) / NPF;
+  int it2 = (KF1 - NPF + 1 - base + NPF - 1) / NPF;
+  it1 = min(max(it1, 0), NIT);
+  it2 = min(max(it2, it1), NIT);
+
+  int it = 0;
+  for (; it < it1; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
+  }
+  if (it < it2) {
+    __builtin_amdgcn_s_waitcnt(kVmcnt0);
+    for (; it < it2; ++it) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) slot_fast(base + NPF * it + u, rg[u]);
     }
   }
+  for (; it < NIT; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
+  }
+#ifdef FTR_STAMPS
+  if (b == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 6; ++i) g_stamps[8 + i] = st_acc[i];
+#endif
 }
 
 inline size_t wave_lds_bytes(int NW) {
@@ -529,6 +725,13 @@ __global__ void selftest_kernel(const float* __restrict__ in, float* __restrict_
 }
 
 }  // namespace
+
+int debug_stamps(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) {
+    set_error("debug_stamps: hipMemcpyFromSymbol failed"); return FTR_ERR_LAUNCH;
+  }
+  return FTR_OK;
+}
 
 int selftest(hipStream_t st, int* result_dev) {
   // scratch lives behind result_dev: [0] result int, then 512 floats in, 512 floats out

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ftr_pruned_logprobs_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_logprobs_bwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_selftest": (_i, [ctypes.c_void_p, _c_st]),
+    "ftr_debug_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
