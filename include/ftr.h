@@ -39,9 +39,11 @@ int ftr_abi_version(void);
 const char* ftr_package_version(void);
 /* Thread-local description of the last non-success return on this thread ("" if none). */
 const char* ftr_last_error(void);
-/* Selects the mutual-information kernel family: 0 = "wavefront" (default, skewed wave64 DP with LDS
- * staged tiles), 1 = "plain" (one thread per lattice row, reference arithmetic; diagnostic).  Also
- * settable with the environment variable FTR_MI_IMPL=wavefront|plain.  Returns the previous value. */
+/* Selects the mutual-information kernel family: 0 = "wavefront" (default: skewed wave64 DP, compute/IO wave
+ * pairs, LDS staged tiles), 1 = "plain" (one thread per lattice row, reference arithmetic; diagnostic),
+ * 2 = "mono" (wavefront kernels without the compute/IO split, normally used only above 384 lattice rows;
+ * diagnostic).  Also settable with the environment variable FTR_MI_IMPL=wavefront|plain|mono.  Returns the
+ * previous value. */
 int ftr_set_mi_impl(int impl);
 int ftr_get_mi_impl(void);
 
@@ -130,6 +132,34 @@ int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, con
                                 const float* gpx, const float* gpy, const float* scale,
                                 float* glogits, int B, int T, int S, int C, int r, int modified,
                                 void* stream);
+
+/*
+ * Simple-loss px/py builder (joiner = addition).  Replaces get_rnnt_logprobs (rnnt_loss.py:63-223), fix_for_boundary
+ * (:28-61), the delay-penalty block (:305-321) and their autodiff, except for the three dense contractions, which
+ * the host issues as library GEMMs between these calls (forward: prod = lm_probs @ am_probs^T [B,S+1,T]; backward:
+ * dlmp = W @ am_probs [B,S+1,C], damp = W^T @ lm_probs [B,T,C]).
+ *   ftr_rowmax_exp_f32          probs[row,:] = exp(x[row,:] - max), rowmax[row] = max            (:175-178)
+ *   ftr_simple_logprobs_fwd_f32 px [B,S,T+1|T], py [B,S+1,T] from am [B,T,C], lm [B,S+1,C], symbols [B,S],
+ *                               prod, am_max [B,T], lm_max [B,S+1]; -inf column / boundary column / penalty fused
+ *   ftr_simple_logprobs_bwd_w_f32   W = -(gpx' + gpy)/(prod + tiny) [B,S+1,T]; rsx, rsy [B,S+1] row sums
+ *   ftr_simple_logprobs_bwd_am_f32  d am [B,T,C] = damp*am_probs + scatter_s gpx'[b,s,t] -> column symbols[b,s]
+ *                                   + blank column sums of gpy
+ *   ftr_simple_logprobs_bwd_lm_f32  d lm [B,S+1,C] = dlmp*lm_probs + rsx at the symbol column + rsy at blank
+ * gpx' = gpx with the cells the forward overwrote with -inf (t == T, t == t_end; regular only) masked out.
+ */
+int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long rows, int C, void* stream);
+int ftr_simple_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                                const float* am_max, const float* lm_max, const int32_t* boundary,
+                                int termination_symbol, double delay_penalty, float* px, float* py, int B, int T,
+                                int S, int C, int modified, void* stream);
+int ftr_simple_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
+                                  float* W, float* rsx, float* rsy, int B, int T, int S, int modified, void* stream);
+int ftr_simple_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
+                                   const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                   float* d_am, int B, int T, int S, int C, int modified, void* stream);
+int ftr_simple_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, const int32_t* symbols,
+                                   const float* rsx, const float* rsy, int termination_symbol, float* d_lm, int B,
+                                   int S, int C, void* stream);
 
 /* Hardware self-test used by smoke()/tests: checks on the device that the primitives the wavefront
  * kernels rely on behave as assumed (full-wave DPP shift wave_shr:1 with lane 0 keeping its old value;

@@ -56,6 +56,9 @@ if __name__ == "__main__":
     _lib.lib().ftr_debug_stamps(buf)
     v = list(buf)
     if any(v):
+        # duo kernels: [0..2] fwd compute wave (compute, barrier wait, slots), [3..7] fwd IO wave (park, drain, loads, barrier, slots)
+        #              [8..10] bwd compute wave, [11..15] bwd IO wave
         for name, o in (("fwd", 0), ("bwd", 8)):
-            n = max(v[o + 5], 1)
-            print(name, "per-slot cycles: compute %.0f  refill %.0f  stores %.0f  loads %.0f  barrier %.0f  (slots %d)" % tuple([v[o + i] / n for i in range(5)] + [n]))
+            n = max(v[o + 2], 1); m = max(v[o + 7], 1)
+            print(f"{name} compute wave per slot: compute {v[o]/n:.0f}  barrier-wait {v[o+1]/n:.0f} cycles ({n} slots);  "
+                  f"IO wave per slot: park {v[o+3]/m:.0f}  drain {v[o+4]/m:.0f}  loads {v[o+5]/m:.0f}  barrier-wait {v[o+6]/m:.0f} ({m} slots)")

@@ -16,7 +16,7 @@ from helpers import max_rel, random_lattice
 
 pytestmark = pytest.mark.gpu
 
-IMPLS = {"wavefront": 0, "plain": 1}
+IMPLS = {"wavefront": 0, "plain": 1, "mono": 2}
 
 
 def _run(ft, dev, px, py, bd, impl, need_grads=True):
@@ -40,10 +40,10 @@ def test_selftest(ft, dev):
     assert int(scratch[0].item()) == 1
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
 @pytest.mark.parametrize("modified", [False, True])
 @pytest.mark.parametrize("shape", [(2, 4, 8), (3, 1, 1), (3, 7, 10), (4, 50, 200), (2, 63, 70), (2, 64, 65),
-                                   (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40)])
+                                   (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40), (2, 383, 150), (2, 400, 130)])
 def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
     B, S, T = shape
     px, py, bd = random_lattice(100 + S + T, B, S, T, modified=modified, ragged=True)
@@ -66,7 +66,7 @@ def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
         assert not gx[b, :, te + 1:].any() and not gy[b, :, te:].any()
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
 @pytest.mark.parametrize("modified", [False, True])
 def test_mi_begin_offsets_and_empty(ft, dev, oracle, impl, modified):
     B, S, T = 5, 20, 37
@@ -82,7 +82,7 @@ def test_mi_begin_offsets_and_empty(ft, dev, oracle, impl, modified):
     assert max_rel(gx[ok], o_gx[ok]) <= 1e-4 and max_rel(gy[ok], o_gy[ok]) <= 1e-4
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
 @pytest.mark.parametrize("modified", [False, True])
 @pytest.mark.parametrize("frac", [0.02, 0.3])
 def test_mi_neg_inf_entries(ft, dev, oracle, impl, modified, frac):
@@ -109,7 +109,7 @@ def test_mi_boundary_none(ft, dev, oracle):
     assert max_rel(gx, o_gx) <= 1e-4 and max_rel(gy, o_gy) <= 1e-4
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
 def test_mi_vs_float64_oracle_long(ft, dev, oracle, impl):
     """Long lattice with realistic magnitudes (px,py ~ log(1/C)): compare with the float64 oracle and
     require the native result to be no worse than the float32 reference arithmetic."""
@@ -157,7 +157,7 @@ def test_mi_full_size_properties(ft, dev):
     bd[1, 2] = 77; bd[1, 3] = 513; bd[2, 2] = 199; bd[2, 3] = 999
     px = px.scatter(2, bd[:, 3].long().reshape(B, 1, 1).expand(B, S, 1), float("-inf"))
     outs = {}
-    for impl in ("wavefront", "plain"):
+    for impl in ("wavefront", "plain", "mono"):
         outs[impl] = _run(ft, dev, px.numpy(), py.numpy(), bd.numpy(), impl)
     for impl, (ans, gx, gy, chk) in outs.items():
         tol = 1e-2 if impl == "plain" else 1e-4     # plain = reference arithmetic: its normalisation drifts (3e-3 here)
@@ -167,6 +167,8 @@ def test_mi_full_size_properties(ft, dev):
             np.testing.assert_allclose(gx[b, :se, :te + 1].sum(axis=1), 1.0, rtol=tol)
         np.testing.assert_allclose(chk, 1.0, rtol=tol)
     np.testing.assert_allclose(outs["wavefront"][0], outs["plain"][0], rtol=1e-5)
+    np.testing.assert_allclose(outs["wavefront"][0], outs["mono"][0], rtol=1e-6)
+    assert max_rel(outs["wavefront"][1], outs["mono"][1]) <= 1e-5 and max_rel(outs["wavefront"][2], outs["mono"][2]) <= 1e-5
     # plain = the reference arithmetic, whose float32 noise at this size is ~7e-3
     assert max_rel(outs["wavefront"][1], outs["plain"][1]) <= 2e-2
     assert max_rel(outs["wavefront"][2], outs["plain"][2]) <= 2e-2

@@ -194,3 +194,44 @@ def test_full_size_pruned_step_properties(ft, dev):
     g = out["logits_grad"]
     assert torch.isfinite(g).all() and torch.isfinite(out["pruned_loss"]).all()
     np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
+@pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7)])
+def test_native_simple_builder_forward_backward(ft, dev, oracle, rnnt_type, cfg):
+    """get_rnnt_logprobs (native prologue/epilogue kernels around the GEMM): px/py against the oracle with the exact
+    -inf pattern; d/d am and d/d lm against float64 autograd through the op-by-op torch restatement."""
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_torch
+    B, T, S, C = cfg
+    d = synthetic(11, B, T, S, C, ragged=True)
+    am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+    sym = _t(d["symbols"], dev); bd = _t(d["boundary"], dev)
+    px, py = ft.get_rnnt_logprobs(lm, am, sym, d["termination_symbol"], rnnt_type, bd)
+    o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], d["termination_symbol"], rnnt_type, d["boundary"])
+    pxn = px.detach().cpu().numpy(); pyn = py.detach().cpu().numpy()
+    assert pxn.shape == o_px.shape and pyn.shape == o_py.shape
+    assert np.array_equal(np.isneginf(pxn), np.isneginf(o_px))
+    fin = np.isfinite(o_px)
+    np.testing.assert_allclose(pxn[fin], o_px[fin], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(pyn, o_py, rtol=1e-5, atol=2e-5)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    wx = torch.randn(px.shape, generator=g).to(dev); wy = torch.randn(py.shape, generator=g).to(dev)
+    finite = torch.isfinite(px.detach())
+    (torch.where(finite, px, torch.zeros_like(px)) * wx).sum().add((py * wy).sum()).backward()
+    am64 = am.detach().double().requires_grad_(True); lm64 = lm.detach().double().requires_grad_(True)
+    px64, py64 = _get_rnnt_logprobs_torch(lm64, am64, sym, d["termination_symbol"], rnnt_type, bd)
+    (torch.where(finite, px64, torch.zeros_like(px64)) * wx.double()).sum().add((py64 * wy.double()).sum()).backward()
+    assert max_rel(am.grad.cpu().numpy(), am64.grad.cpu().numpy()) <= 1e-4
+    assert max_rel(lm.grad.cpu().numpy(), lm64.grad.cpu().numpy()) <= 1e-4
+
+
+def test_native_simple_builder_odd_vocab_and_penalty(ft, dev, oracle):
+    """C not a multiple of 4 (scalar row path) and the fused delay penalty of rnnt_loss_simple."""
+    d = synthetic(12, 2, 19, 6, 11, ragged=True)
+    args = (_t(d["lm"], dev), _t(d["am"], dev), _t(d["symbols"], dev), d["termination_symbol"])
+    for rt in ("regular", "modified", "constrained"):
+        got = ft.rnnt_loss_simple(*args, boundary=_t(d["boundary"], dev), rnnt_type=rt, delay_penalty=0.3, reduction="none")
+        want = oracle.rnnt_loss_simple(d["lm"], d["am"], d["symbols"], d["termination_symbol"], d["boundary"], rt, 0.3, "none")
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ft.get_rnnt_logprobs(_t(d["lm"], "cpu"), _t(d["am"], "cpu"), _t(d["symbols"], "cpu"), d["termination_symbol"])

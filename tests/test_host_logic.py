@@ -18,9 +18,10 @@ def _t(a):
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
-def test_get_rnnt_logprobs(ft, oracle, rnnt_type):
+def test_get_rnnt_logprobs_torch_restatement(ft, oracle, rnnt_type):
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_torch
     d = synthetic(0, 3, 11, 6, 9, ragged=True)
-    px, py = ft.get_rnnt_logprobs(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"], rnnt_type, _t(d["boundary"]))
+    px, py = _get_rnnt_logprobs_torch(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"], rnnt_type, _t(d["boundary"]))
     o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], d["termination_symbol"], rnnt_type, d["boundary"])
     assert np.array_equal(np.isneginf(px.numpy()), np.isneginf(o_px))
     fin = np.isfinite(o_px)

@@ -23,7 +23,7 @@ int device_ok() {
 int mi_impl() {
   if (g_mi_impl < 0) {
     const char* e = getenv("FTR_MI_IMPL");
-    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : 0;
+    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : (e && strcmp(e, "mono") == 0) ? 2 : 0;
   }
   return g_mi_impl;
 }
@@ -56,7 +56,7 @@ const char* ftr_last_error(void) { return g_err; }
 
 int ftr_set_mi_impl(int impl) {
   const int prev = mi_impl();
-  g_mi_impl = impl ? 1 : 0;
+  g_mi_impl = (impl == 1 || impl == 2) ? impl : 0;
   return prev;
 }
 int ftr_get_mi_impl(void) { return mi_impl(); }
@@ -77,7 +77,7 @@ int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (mi_impl() == 1) return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
-  return mi_wave_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
+  return mi_wave_fwd(px, py, boundary, p, ans, B, S, T, modified, mi_impl() == 2, st);
 }
 
 int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32_t* boundary,
@@ -96,7 +96,7 @@ int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32
     FTR_REQUIRE(px && py, "mutual_information_bwd: the plain family needs px and py");
     return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
   }
-  return mi_wave_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
+  return mi_wave_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, mi_impl() == 2, st);
 }
 
 int ftr_cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, void* stream) {
@@ -163,6 +163,67 @@ int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, con
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   return pruned_logprobs_bwd(logits, symbols, ranges, boundary, termination_symbol, lse, gpx, gpy, scale, glogits, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long rows, int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows >= 0 && C >= 0, "rowmax_exp: negative size");
+  if (rows == 0 || C == 0) return FTR_OK;
+  FTR_REQUIRE(x && probs && rowmax, "rowmax_exp: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_rowmax_exp(x, probs, rowmax, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_simple_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                                const float* am_max, const float* lm_max, const int32_t* boundary,
+                                int termination_symbol, double delay_penalty, float* px, float* py, int B, int T,
+                                int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "simple_logprobs_fwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "simple_logprobs_fwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(am && lm && prod && am_max && lm_max && py && (symbols || S == 0) && (px || S == 0), "simple_logprobs_fwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_fwd(am, lm, symbols, prod, am_max, lm_max, boundary, termination_symbol, delay_penalty, px, py, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_simple_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
+                                  float* W, float* rsx, float* rsy, int B, int T, int S, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0, "simple_logprobs_bwd_w: bad sizes");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "simple_logprobs_bwd_w: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_w(gpx, gpy, prod, boundary, W, rsx, rsy, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_simple_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
+                                   const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                   float* d_am, int B, int T, int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "simple_logprobs_bwd_am: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "simple_logprobs_bwd_am: bad termination_symbol");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && damp && am_probs && d_am && (gpx || S == 0) && (symbols || S == 0), "simple_logprobs_bwd_am: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_am(gpx, gpy, damp, am_probs, symbols, boundary, termination_symbol, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_simple_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, const int32_t* symbols,
+                                   const float* rsx, const float* rsy, int termination_symbol, float* d_lm, int B,
+                                   int S, int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 0 && C >= 1, "simple_logprobs_bwd_lm: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "simple_logprobs_bwd_lm: bad termination_symbol");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(dlmp && lm_probs && rsx && rsy && d_lm && (symbols || S == 0), "simple_logprobs_bwd_lm: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_lm(dlmp, lm_probs, symbols, rsx, rsy, termination_symbol, d_lm, B, S, C, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_selftest(void* scratch_dev, void* stream) {

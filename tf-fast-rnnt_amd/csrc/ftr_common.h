@@ -50,13 +50,18 @@ __device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ bound
 namespace ftr {
 int mi_plain_fwd(const float* px, const float* py, const int32_t* boundary, float* p, float* ans, int B, int S, int T, int modified, hipStream_t st);
 int mi_plain_bwd(const float* px, const float* py, const int32_t* boundary, const float* p, float* p_grad, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
-int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
-int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
+int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, int force_mono, hipStream_t st);
+int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, int force_mono, hipStream_t st);
 int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st);
 int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boundary, int32_t* ranges, int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st);
 int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1, int C, int r, hipStream_t st);
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, const float* scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
+int simple_rowmax_exp(const float* x, float* probs, float* rowmax, size_t rows, int C, hipStream_t st);
+int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols, const float* prod, const float* am_max, const float* lm_max, const int32_t* boundary, int blank, double delay_penalty, float* px, float* py, int B, int T, int S, int C, int modified, hipStream_t st);
+int simple_logprobs_bwd_w(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary, float* W, float* rsx, float* rsy, int B, int T, int S, int modified, hipStream_t st);
+int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
+int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx, const float* rsy, int blank, float* d_lm, int B, int S, int C, hipStream_t st);
 int selftest(hipStream_t st, int* result_dev);
 int debug_stamps(unsigned long long* out16);
 }

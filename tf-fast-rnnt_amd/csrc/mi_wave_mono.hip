@@ -1,4 +1,6 @@
-// csrc/mi_wave.hip -- "wavefront" mutual-information kernels for gfx950 (MI355X), the product path.
+// csrc/mi_wave_mono.hip -- "wavefront" mutual-information kernels, single-role variant: every wave does its own
+// staging, recursion and write-out.  Used for lattices of more than 6 row bands (S+1 > 384), where the
+// specialised compute/IO pair of mi_wave_duo.hip does not fit the 160 KB LDS.  The design notes below apply to both.
 //
 // What they compute is the recursion of the reference (tf_fast_rnnt/csrc/mutual_information.h:101-126,
 // mutual_information_cuda.cu:174-422 forward, :441-760 backward); HOW is different by design:
@@ -32,39 +34,11 @@
 //
 // Workspace ("p" in the C ABI): B*(S+1)*(T+1) floats holding G for every in-boundary cell.
 #include "ftr_common.h"
+#include "mi_wave_common.h"
 
 namespace ftr {
+using namespace wavecfg;
 namespace {
-
-constexpr int CH = 16;              // steps per chunk
-constexpr int NQ = CH / 4;          // quads (4 consecutive steps) per chunk
-constexpr int PLANE = 66;           // float4 per [quad] plane: 64 rows + 2 pad (conflict-free fill+read)
-constexpr int TILE_F4 = NQ * PLANE; // one tile = 264 float4 = 4224 B
-// chunks in flight in registers (prefetch distance): 3 where the register budget allows (<= 8 waves per
-// workgroup), 2 for 16-wave workgroups (128 VGPRs per lane, and 4 waves per SIMD hide latency themselves)
-template <int MAXW> struct Prefetch { static constexpr int N = (MAXW <= 8) ? 3 : 2; };
-constexpr int kVmcnt0 = 0x0F70;     // s_waitcnt immediate: vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
-constexpr int RINGN = 64;
-
-// Diagnostic build only (make STAMPS=1): per-segment s_memtime sums of the steady-state slot of wave 0 of
-// workgroup 0, read back through ftr_debug_stamps().  Never compiled into the product library.
-__device__ unsigned long long g_stamps[16];
-#ifdef FTR_STAMPS
-#define FTR_STAMP(var)                                                                            \
-  do {                                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                   \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-  } while (0)
-#else
-#define FTR_STAMP(var) do { } while (0)
-#endif
-
-__device__ __forceinline__ float dpp_wave_shr1(float old_for_lane0, float src) {
-  // lane l (l >= 1) receives src of lane l-1; lane 0 keeps `old_for_lane0` (bound_ctrl = 0).
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_for_lane0),
-                                                               __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
-}
 
 // RING.  Wave w (the "producer") publishes, every 4 steps, the last 4 values of its lane 63 at
 // ring[w+1][(j0 & 63) .. +3], j0 = its local step.  Wave w+1 (the "consumer") needs, at ITS local step
@@ -674,11 +648,11 @@ int launch_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* 
 
 }  // namespace
 
-int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans,
+int mi_mono_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans,
                 int B, int S, int T, int modified, hipStream_t st) {
   const int NW = (S + 1 + 63) / 64;
   if (NW > 16) {
-    set_error("mi_wave_fwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
+    set_error("mi_mono_fwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
     return FTR_ERR_UNSUPPORTED;
   }
 #define FTR_DISPATCH(MODV)                                                                      \
@@ -689,11 +663,11 @@ int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float
 #undef FTR_DISPATCH
 }
 
-int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad,
+int mi_mono_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad,
                 float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st) {
   const int NW = (S + 1 + 63) / 64;
   if (NW > 16) {
-    set_error("mi_wave_bwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
+    set_error("mi_mono_bwd: S+1=%d rows exceed the 1024 rows one workgroup covers (round-1 limit)", S + 1);
     return FTR_ERR_UNSUPPORTED;
   }
 #define FTR_DISPATCH(MODV)                                                                                              \
@@ -702,51 +676,6 @@ int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float*
                      : launch_bwd<MODV, 16>(boundary, ws, px_grad, py_grad, ans_grad, overwrite, B, S, T, NW, st))
   return modified ? FTR_DISPATCH(true) : FTR_DISPATCH(false);
 #undef FTR_DISPATCH
-}
-
-namespace {
-
-// ---------------------------------------------------------------------------------------------
-// Hardware self-test: the wavefront kernels rely on (1) wave_shr:1 DPP shifting across all 64 lanes
-// with lane 0 keeping `old`, (2) 16-byte global loads/stores at 4-byte alignment.  result[0] = 1 if
-// both behave as assumed.
-__global__ void selftest_kernel(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ result) {
-  const int lane = threadIdx.x;
-  const float mine = (float)(lane + 1);
-  const float got = dpp_wave_shr1(-7.0f, mine);
-  const bool ok1 = (lane == 0) ? (got == -7.0f) : (got == (float)lane);
-  // unaligned 16B load at element offset 1 + 5*lane, store at 3 + 5*lane
-  const f4 v = *reinterpret_cast<const f4u*>(in + 1 + 5 * lane);
-  bool ok2 = true;
-  for (int e = 0; e < 4; ++e) ok2 = ok2 && (v[e] == (float)(1 + 5 * lane + e));
-  *reinterpret_cast<f4u*>(out + 3 + 5 * lane) = v;
-  const unsigned long long m = __ballot(ok1 && ok2);
-  if (lane == 0) result[0] = (m == ~0ull) ? 1 : 0;
-}
-
-}  // namespace
-
-int debug_stamps(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) {
-    set_error("debug_stamps: hipMemcpyFromSymbol failed"); return FTR_ERR_LAUNCH;
-  }
-  return FTR_OK;
-}
-
-int selftest(hipStream_t st, int* result_dev) {
-  // scratch lives behind result_dev: [0] result int, then 512 floats in, 512 floats out
-  float* in = reinterpret_cast<float*>(result_dev + 4);
-  float* out = in + 512;
-  float host[512];
-  for (int i = 0; i < 512; ++i) host[i] = (float)i;
-  if (hipMemcpyAsync(in, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) {
-    set_error("selftest: memcpy failed"); return FTR_ERR_LAUNCH;
-  }
-  if (hipStreamSynchronize(st) != hipSuccess) {  // host[] is on the stack
-    set_error("selftest: sync failed"); return FTR_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, in, out, result_dev);
-  return check_launch("selftest");
 }
 
 }  // namespace ftr

@@ -1,0 +1,291 @@
+// csrc/simple_logprobs.hip -- px/py builder of rnnt_loss_simple (joiner = addition), forward and backward,
+// gfx950.  Replaces the ~25 un-fused TensorFlow ops of get_rnnt_logprobs
+// (/root/reference/tf_fast_rnnt/python/tf_fast_rnnt/rnnt_loss.py:175-221), fix_for_boundary (:28-61), the
+// delay-penalty block (:305-321) and what TF autodiff replays for them.  The one dense contraction
+// (normalisers = lm_probs @ am_probs^T, and its two transposes in the backward) stays a library GEMM on the
+// host side ("may stay in the framework's BLAS"); everything around it is here:
+//
+//   rowmax_exp_kernel      :175-178   row max + exp(x - max), one wave per row, 16-byte accesses
+//   simple_fwd_kernel      :180-221, 305-321   log + max add-back, symbol / blank gathers, -inf column,
+//                          fix_for_boundary, penalty; px and py written once, coalesced along t.  am rows of a
+//                          32-frame tile are staged in LDS (row stride C+1: conflict-free column gathers), so
+//                          am is read from HBM exactly once, coalesced (TF transposes am through HBM for this).
+//   simple_bwd_w_kernel    W = -(gpx + gpy) / (prod + tiny)  and the row sums that feed d lm
+//   simple_bwd_am_kernel   d am = (W^T lm_probs) * am_probs + scatter of gpx by symbol + blank column sums;
+//                          the scatter-add over symbols happens in an LDS tile owned by the workgroup
+//                          (each accumulator cell is owned by exactly one thread: deterministic, no atomics)
+//   simple_bwd_lm_kernel   d lm = (W am_probs) * lm_probs + row sums at the symbol / blank columns
+#include "ftr_common.h"
+
+namespace ftr {
+namespace {
+
+constexpr float kTiny = 1.401298464324817e-45f;  // tf.math.nextafter(0., 1.)  (rnnt_loss.py:181)
+constexpr int TT = 32;                           // frames per tile
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// probs[row, :] = exp(x[row, :] - max(x[row, :])), rowmax[row] = max.  One wave per row.
+template <bool VEC>
+__global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict__ probs,
+                                  float* __restrict__ rowmax, size_t rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  float* pr = probs + row * C;
+  float m = -INFINITY;
+  if (VEC) {
+    const f4u* x4 = reinterpret_cast<const f4u*>(xr);
+    f4u* p4 = reinterpret_cast<f4u*>(pr);
+    const int n4 = C >> 2;
+    for (int i = lane; i < n4; i += 64) { const f4 v = x4[i]; m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); }
+    m = wave_max(m);
+    for (int i = lane; i < n4; i += 64) {
+      const f4 v = x4[i];
+      f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = expf(v[e] - m);
+      p4[i] = o;
+    }
+  } else {
+    for (int i = lane; i < C; i += 64) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    for (int i = lane; i < C; i += 64) pr[i] = expf(xr[i] - m);
+  }
+  if (lane == 0) rowmax[row] = m;
+}
+
+// grid (ceil(T1 / TT), B); block 256 = 8 row-groups x 32 frames.  LDS: am tile [TT][C+1].
+template <bool MOD>
+__global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __restrict__ lm,
+                                  const int32_t* __restrict__ symbols, const float* __restrict__ prod,
+                                  const float* __restrict__ am_max, const float* __restrict__ lm_max,
+                                  const int32_t* __restrict__ boundary, int blank, double delay_penalty,
+                                  float* __restrict__ px, float* __restrict__ py, int T, int S, int C) {
+  extern __shared__ float tile[];  // [TT][C + 1]
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int T1 = MOD ? T : T + 1;
+  const int ld = C + 1;
+  const float* amb = am + (size_t)b * T * C;
+  // stage TT frames of am (zeros past T), coalesced along c
+  for (int i = threadIdx.x; i < TT * C; i += blockDim.x) {
+    const int tt = i / C, c = i - tt * C;
+    tile[tt * ld + c] = (t0 + tt < T) ? amb[(size_t)(t0 + tt) * C + c] : 0.0f;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & (TT - 1);
+  const int ty = threadIdx.x >> 5;
+  const int t = t0 + tx;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const float amx = (t < T) ? am_max[(size_t)b * T + t] : 0.0f;
+  const float am_blank = tile[tx * ld + blank];
+  float pen = 0.0f;
+  if (delay_penalty > 0.0) pen = (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty);  // :305-321
+  const float* lmb = lm + (size_t)b * (S + 1) * C;
+  for (int s = ty; s <= S; s += 8) {
+    float nrm = 0.0f;
+    if (t < T) {
+      nrm = logf(prod[((size_t)b * (S + 1) + s) * T + t] + kTiny) + lm_max[(size_t)b * (S + 1) + s] + amx;  // :180-186
+      py[((size_t)b * (S + 1) + s) * T + t] = am_blank + lmb[(size_t)s * C + blank] - nrm;                  // :214-216
+    }
+    if (s < S && t < T1) {
+      float v = -INFINITY;  // px[:, :, T] (:193-203) and fix_for_boundary (:218-219)
+      if (t < T && (MOD || t != te)) {
+        const int sym = symbols[(size_t)b * S + s];
+        v = tile[tx * ld + sym] + lmb[(size_t)s * C + sym] - nrm;                                          // :187-211
+      }
+      if (delay_penalty > 0.0) v += pen;
+      px[((size_t)b * S + s) * T1 + t] = v;
+    }
+  }
+}
+
+// one workgroup per (b, s) row: W[b,s,:] and the two row sums.  rsx[b,s] = sum_t gpx'[b,s,t] (0 for s == S),
+// rsy[b,s] = sum_t gpy[b,s,t]; gpx' = gpx with the overwritten cells (t == T, t == t_end) masked.
+template <bool MOD>
+__global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
+                                    const float* __restrict__ prod, const int32_t* __restrict__ boundary,
+                                    float* __restrict__ W, float* __restrict__ rsx, float* __restrict__ rsy,
+                                    int T, int S) {
+  __shared__ float red[2][4];
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int T1 = MOD ? T : T + 1;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const size_t rowy = ((size_t)b * (S + 1) + s) * T;
+  const size_t rowx = ((size_t)b * S + s) * T1;
+  float sx = 0.0f, sy = 0.0f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float gx = 0.0f;
+    if (s < S && (MOD || t != te)) gx = gpx[rowx + t];
+    const float gy = gpy[rowy + t];
+    sx += gx; sy += gy;
+    W[rowy + t] = -(gx + gy) / (prod[rowy + t] + kTiny);
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = sx; red[1][wv] = sy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c = 0.0f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += red[0][i]; c += red[1][i]; }
+    rsx[(size_t)b * (S + 1) + s] = a;
+    rsy[(size_t)b * (S + 1) + s] = c;
+  }
+}
+
+// grid (ceil(T / TT), B); block 256 = 8 column-owner groups x 32 frames.  LDS: acc [TT][C + 1] + csy[8][TT].
+// Thread (ty, tx) owns the accumulator cells acc[tx][c] with c % 8 == ty: every cell has one owner.
+template <bool MOD>
+__global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
+                                     const float* __restrict__ damp, const float* __restrict__ am_probs,
+                                     const int32_t* __restrict__ symbols, const int32_t* __restrict__ boundary,
+                                     int blank, float* __restrict__ d_am, int T, int S, int C) {
+  extern __shared__ float acc[];  // [TT][C + 1], then csy [8][TT]
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int T1 = MOD ? T : T + 1;
+  const int ld = C + 1;
+  float* csy = acc + TT * ld;
+  for (int i = threadIdx.x; i < TT * ld; i += blockDim.x) acc[i] = 0.0f;
+  __syncthreads();
+  const int tx = threadIdx.x & (TT - 1);
+  const int ty = threadIdx.x >> 5;
+  const int t = t0 + tx;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const bool tok = t < T;
+  const bool xok = tok && (MOD || t != te);
+  const int32_t* symb = symbols + (size_t)b * S;
+  float cs = 0.0f;
+  for (int s = 0; s < S; ++s) {
+    const int sym = symb[s];
+    if ((sym & 7) == ty && xok) acc[tx * ld + sym] += gpx[((size_t)b * S + s) * T1 + t];
+  }
+  for (int s = ty; s <= S; s += 8)
+    if (tok) cs += gpy[((size_t)b * (S + 1) + s) * T + t];
+  csy[ty * TT + tx] = cs;
+  __syncthreads();
+  // write-out, coalesced along c
+  for (int i = threadIdx.x; i < TT * C; i += blockDim.x) {
+    const int tt = i / C, c = i - tt * C;
+    if (t0 + tt < T) {
+      const size_t o = ((size_t)b * T + t0 + tt) * C + c;
+      float v = damp[o] * am_probs[o] + acc[tt * ld + c];
+      if (c == blank) {
+        float col = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) col += csy[g * TT + tt];
+        v += col;
+      }
+      d_am[o] = v;
+    }
+  }
+}
+
+// one thread per element of d lm [B, S+1, C]
+__global__ void simple_bwd_lm_kernel(const float* __restrict__ dlmp, const float* __restrict__ lm_probs,
+                                     const int32_t* __restrict__ symbols, const float* __restrict__ rsx,
+                                     const float* __restrict__ rsy, int blank, float* __restrict__ d_lm, int S,
+                                     int C, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / C;  // b*(S+1) + s
+    const int c = (int)(i - row * C);
+    const int s = (int)(row % (size_t)(S + 1));
+    const size_t b = row / (size_t)(S + 1);
+    float v = dlmp[i] * lm_probs[i];
+    if (s < S && c == symbols[b * S + s]) v += rsx[row];
+    if (c == blank) v += rsy[row];
+    d_lm[i] = v;
+  }
+}
+
+}  // namespace
+
+int simple_rowmax_exp(const float* x, float* probs, float* rowmax, size_t rows, int C, hipStream_t st) {
+  if (rows == 0 || C == 0) return FTR_OK;
+  const int wpb = 4;
+  const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
+  if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rows, C);
+  else hipLaunchKernelGGL(rowmax_exp_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rows, C);
+  return check_launch("rowmax_exp");
+}
+
+static int tile_lds_ok(size_t lds, const char* what) {
+  if (lds > 160 * 1024) { set_error("%s: C too large for the LDS tile (%zu bytes)", what, lds); return FTR_ERR_UNSUPPORTED; }
+  return FTR_OK;
+}
+
+template <typename K>
+static int reserve_lds(K kernel, size_t lds, const char* what) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("%s: cannot reserve %zu bytes of LDS: %s", what, lds, hipGetErrorString(e)); return FTR_ERR_LAUNCH; }
+  }
+  return FTR_OK;
+}
+
+int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                        const float* am_max, const float* lm_max, const int32_t* boundary, int blank,
+                        double delay_penalty, float* px, float* py, int B, int T, int S, int C, int modified,
+                        hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)TT * (C + 1);
+  int rc = tile_lds_ok(lds, "simple_logprobs_fwd");
+  if (rc != FTR_OK) return rc;
+  const int T1 = modified ? T : T + 1;
+  const dim3 grid((T1 + TT - 1) / TT, B);
+  if (modified) {
+    if ((rc = reserve_lds(simple_fwd_kernel<true>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(simple_fwd_kernel<true>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, px, py, T, S, C);
+  } else {
+    if ((rc = reserve_lds(simple_fwd_kernel<false>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(simple_fwd_kernel<false>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, px, py, T, S, C);
+  }
+  return check_launch("simple_logprobs_fwd");
+}
+
+int simple_logprobs_bwd_w(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
+                          float* W, float* rsx, float* rsy, int B, int T, int S, int modified, hipStream_t st) {
+  const dim3 grid(S + 1, B);
+  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, T, S);
+  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, T, S);
+  return check_launch("simple_logprobs_bwd_w");
+}
+
+int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
+                           const int32_t* symbols, const int32_t* boundary, int blank, float* d_am, int B, int T,
+                           int S, int C, int modified, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 8 * TT);
+  int rc = tile_lds_ok(lds, "simple_logprobs_bwd_am");
+  if (rc != FTR_OK) return rc;
+  const dim3 grid((T + TT - 1) / TT, B);
+  if (modified) {
+    if ((rc = reserve_lds(simple_bwd_am_kernel<true>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(simple_bwd_am_kernel<true>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, d_am, T, S, C);
+  } else {
+    if ((rc = reserve_lds(simple_bwd_am_kernel<false>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
+    hipLaunchKernelGGL(simple_bwd_am_kernel<false>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, d_am, T, S, C);
+  }
+  return check_launch("simple_logprobs_bwd_am");
+}
+
+int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx,
+                           const float* rsy, int blank, float* d_lm, int B, int S, int C, hipStream_t st) {
+  const size_t total = (size_t)B * (S + 1) * C;
+  if (total == 0) return FTR_OK;
+  const size_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(simple_bwd_lm_kernel, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0, st,
+                     dlmp, lm_probs, symbols, rsx, rsy, blank, d_lm, S, C, total);
+  return check_launch("simple_logprobs_bwd_lm");
+}
+
+}  // namespace ftr

@@ -34,6 +34,11 @@ _SIGNATURES = {
     "ftr_do_pruning_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_logprobs_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_logprobs_bwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_rowmax_exp_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
+    "ftr_simple_logprobs_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_simple_logprobs_bwd_w_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
+    "ftr_simple_logprobs_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_simple_logprobs_bwd_lm_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _c_fp, _i, _i, _i, _c_st]),
     "ftr_selftest": (_i, [ctypes.c_void_p, _c_st]),
     "ftr_debug_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
 }

@@ -6,8 +6,9 @@ What runs where:
 * ``mutual_information_recursion`` (every loss ends there), ``get_rnnt_prune_ranges``,
   ``do_rnnt_pruning``, ``get_rnnt_logprobs_pruned`` / ``rnnt_loss_pruned``: hand-written HIP behind the
   C ABI (include/ftr.h);
-* the simple / smoothed / joint px,py builders: torch ops for now (normaliser contraction through
-  rocBLAS) -- SURVEY.md 8(f) row 1, "next".
+* ``get_rnnt_logprobs`` / ``rnnt_loss_simple``: hand-written HIP prologue, epilogue and backward kernels around
+  the normaliser GEMM (rocBLAS through torch.bmm);
+* the smoothed and joint (unpruned) px,py builders: torch ops for now -- SURVEY.md 8(f), "next".
 
 Reference bugs that are NOT reproduced: ``rnnt_loss_simple(reduction="mean")``
 raises NameError there (rnnt_loss.py:331) -- here it is the mean; ``boundary=None`` works; the
@@ -58,6 +59,85 @@ def _normalizers(lm: torch.Tensor, am: torch.Tensor):
     return normalizers, am_max, lm_max, am_probs, lm_probs
 
 
+class _SimpleLogprobs(torch.autograd.Function):
+    """get_rnnt_logprobs (+ fix_for_boundary + delay penalty) for regular/modified: native prologue and
+    epilogue kernels around the normaliser GEMM (torch.bmm -> rocBLAS), hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, delay_penalty):
+        B, T, C = am.shape
+        S = lm.shape[1] - 1
+        T1 = T if modified else T + 1
+        amc = am.detach().contiguous(); lmc = lm.detach().contiguous()
+        dev = amc.device
+        am_probs = torch.empty_like(amc); lm_probs = torch.empty_like(lmc)
+        am_max = torch.empty((B, T), dtype=torch.float32, device=dev)
+        lm_max = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        px = torch.empty((B, S, T1), dtype=torch.float32, device=dev)
+        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(amc)
+            _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)        # :175-178
+            _lib.call("ftr_rowmax_exp_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
+            prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                         # :180-182
+            _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
+                      _ptr(lm_max), _ptr(boundary), int(termination_symbol), float(delay_penalty), _ptr(px), _ptr(py),
+                      B, T, S, C, int(modified), st)
+        ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0))
+        ctx.has_boundary = boundary is not None
+        ctx.meta = (int(termination_symbol), int(modified))
+        return px, py
+
+    @staticmethod
+    def backward(ctx, gpx, gpy):
+        am_probs, lm_probs, prod, symbols, boundary = ctx.saved_tensors
+        if not ctx.has_boundary:
+            boundary = None
+        blank, modified = ctx.meta
+        B, T, C = am_probs.shape
+        S = lm_probs.shape[1] - 1
+        dev = am_probs.device
+        gpx = gpx.contiguous(); gpy = gpy.contiguous()
+        W = torch.empty_like(prod)
+        rsx = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        rsy = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        d_am = torch.empty_like(am_probs); d_lm = torch.empty_like(lm_probs)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(am_probs)
+            _lib.call("ftr_simple_logprobs_bwd_w_f32", _ptr(gpx), _ptr(gpy), _ptr(prod), _ptr(boundary), _ptr(W),
+                      _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
+            dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+            damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
+            _lib.call("ftr_simple_logprobs_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(damp), _ptr(am_probs), _ptr(symbols),
+                      _ptr(boundary), blank, _ptr(d_am), B, T, S, C, modified, st)
+            _lib.call("ftr_simple_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx), _ptr(rsy),
+                      blank, _ptr(d_lm), B, S, C, st)
+        return d_lm, d_am, None, None, None, None, None
+
+
+def _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary, delay_penalty=0.0):
+    _require_gpu(am, "am"); _require_gpu(lm, "lm")
+    if am.dtype != torch.float32 or lm.dtype != torch.float32:
+        raise TypeError("am and lm must be float32")
+    B, T, C = am.shape
+    S = lm.shape[1] - 1
+    if lm.shape[0] != B or lm.shape[2] != C:
+        raise ValueError(f"lm {tuple(lm.shape)} and am {tuple(am.shape)} disagree")
+    symbols = torch.as_tensor(symbols, device=am.device)
+    if tuple(symbols.shape) != (B, S):
+        raise ValueError(f"symbols must have shape {(B, S)}, got {tuple(symbols.shape)}")
+    if not 0 <= int(termination_symbol) < C:
+        raise ValueError(f"termination_symbol {termination_symbol} not in [0, {C})")
+    symbols = symbols.to(torch.int32).contiguous()
+    boundary = _as_boundary(boundary, B, am.device)
+    modified = rnnt_type != "regular"
+    pen = float(delay_penalty) if delay_penalty > 0.0 else 0.0
+    px, py = _SimpleLogprobs.apply(lm, am, symbols, termination_symbol, boundary, modified, pen)
+    if rnnt_type == "constrained":
+        px = px + py[:, 1:, :]
+    return px, py
+
+
 def get_rnnt_logprobs(
     lm: torch.Tensor,
     am: torch.Tensor,
@@ -66,7 +146,16 @@ def get_rnnt_logprobs(
     rnnt_type: str = "regular",
     boundary: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """rnnt_loss.py:63-223.  lm [B,S+1,C], am [B,T,C], symbols [B,S] -> px [B,S,T+1|T], py [B,S+1,T]."""
+    """rnnt_loss.py:63-223.  lm [B,S+1,C], am [B,T,C], symbols [B,S] -> px [B,S,T+1|T], py [B,S+1,T].
+    Native (HIP) prologue/epilogue around one library GEMM; differentiable w.r.t. lm and am."""
+    _check_type(rnnt_type)
+    return _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary)
+
+
+def _get_rnnt_logprobs_torch(lm, am, symbols, termination_symbol, rnnt_type="regular", boundary=None):
+    """The same function op by op in torch (the shape the reference has it in, rnnt_loss.py:163-223).  Not on
+    the product path: kept as an independent restatement for the tests and for the smoothed variant's shared
+    pieces."""
     _check_type(rnnt_type)
     B, T, C = am.shape
     S = lm.shape[1] - 1
@@ -138,10 +227,13 @@ def rnnt_loss_simple(
     calc_gradients: bool = False,
 ) -> Union[torch.Tensor, Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]]:
     """rnnt_loss.py:225-338.  Returns loss, or (loss, (px_grad, py_grad)) when ``calc_gradients``."""
+    _check_type(rnnt_type)
     boundary = _as_boundary(boundary, am.shape[0], am.device)
-    px, py = get_rnnt_logprobs(lm=lm, am=am, symbols=symbols, termination_symbol=termination_symbol,
-                               boundary=boundary, rnnt_type=rnnt_type)
-    px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
+    if rnnt_type == "constrained":   # the penalty applies after px += py[:, 1:, :]  (:218-221, :305-321)
+        px, py = _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary)
+        px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
+    else:
+        px, py = _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary, delay_penalty)
     return _drive(px, py, boundary, reduction, calc_gradients)
 
 
