@@ -39,17 +39,18 @@ int ftr_abi_version(void);
 const char* ftr_package_version(void);
 /* Thread-local description of the last non-success return on this thread ("" if none). */
 const char* ftr_last_error(void);
-/* Selects the mutual-information kernel family: 0 = "wavefront" (default: skewed wave64 DP, compute/IO wave
- * pairs, LDS staged tiles), 1 = "plain" (one thread per lattice row, reference arithmetic; diagnostic),
- * 2 = "mono" (wavefront kernels without the compute/IO split, normally used only above 384 lattice rows;
- * diagnostic).  Also settable with the environment variable FTR_MI_IMPL=wavefront|plain|mono.  Returns the
- * previous value. */
+/* Selects the mutual-information kernel family: 0 = "wavefront" (default: skewed wave64 DP, one workgroup per
+ * 64-row band, bands chained through tagged granules; mi_wave_chain.hip), 1 = "plain" (one thread per lattice
+ * row, reference arithmetic), 2 = "mono", 3 = "duo" (earlier single-workgroup wavefront variants, kept for
+ * bisecting: mono up to 1024 rows, duo up to 384).  Also settable with FTR_MI_IMPL=wavefront|plain|mono|duo.
+ * Returns the previous value. */
 int ftr_set_mi_impl(int impl);
 int ftr_get_mi_impl(void);
 
-/* Number of floats of fwd->bwd workspace (`p` below) for a problem size: B*(S+1)*(T+1), the shape
- * of the reference's temp `p` (tf_fast_rnnt_op.cc:65-67).  Its CONTENT is implementation defined
- * (see DESIGN.md): the same buffer must be handed unchanged from _fwd to _bwd. */
+/* Number of floats of fwd->bwd workspace (`p` below) for a problem size: B*(S+1)*(T+1) -- the shape of the
+ * reference's temp `p` (tf_fast_rnnt_op.cc:65-67) -- plus a small inter-workgroup hand-off region.  Its CONTENT
+ * is implementation defined: the same buffer must be handed unchanged from _fwd to _bwd (the
+ * backward reuses the hand-off region as scratch).  Must be 8-byte aligned. */
 size_t ftr_mutual_information_workspace_floats(int B, int S, int T);
 
 /*
@@ -105,6 +106,12 @@ int ftr_prune_ranges_i32(const float* px_grad, const float* py_grad, const int32
  * am [B,T,C], lm [B,S1,C], ranges [B,T,r]; outputs [B,T,r,C]. */
 int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, float* am_pruned,
                        float* lm_pruned, int B, int T, int S1, int C, int r, void* stream);
+
+/* Backward of the prune gather (TF autodiff of rnnt_loss.py:802-811): d_am[b,t,:] = sum_k g_am_pruned[b,t,k,:];
+ * d_lm[b,s,:] = sum over {(t,k): ranges[b,t,k] == s} of g_lm_pruned[b,t,k,:] in increasing (t,k) order
+ * (deterministic; no atomics).  d_am [B,T,C] and d_lm [B,S1,C] are fully written. */
+int ftr_do_pruning_bwd_f32(const float* g_am_pruned, const float* g_lm_pruned, const int32_t* ranges, float* d_am,
+                           float* d_lm, int B, int T, int S1, int C, int r, void* stream);
 
 /*
  * Pruned log-probs, forward.  Replaces get_rnnt_logprobs_pruned for rnnt_type "regular"

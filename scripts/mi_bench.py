@@ -18,8 +18,8 @@ def run(B, S, T, iters=20, impl=0, cold=False):
     bd = torch.zeros((B, 4), dtype=torch.int32); bd[:, 2] = S; bd[:, 3] = T
     px[:, :, T] = float("-inf")
     bd = bd.to(dev)
-    ws = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=dev)
-    pg = torch.empty_like(ws) if impl == 1 else None
+    ws = torch.empty(L.ftr_mutual_information_workspace_floats(B, S, T), dtype=torch.float32, device=dev)
+    pg = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=dev) if impl == 1 else None
     ans = torch.empty(B, device=dev); ag = torch.ones(B, device=dev)
     gx = torch.empty_like(px); gy = torch.empty_like(py)
     st = torch.cuda.current_stream().cuda_stream

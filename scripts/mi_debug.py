@@ -17,7 +17,7 @@ tpx, tpy, tbd = (torch.from_numpy(a).to(dev) for a in (px, py, bd))
 st = torch.cuda.current_stream().cuda_stream
 def fwd(impl):
     L.ftr_set_mi_impl(impl)
-    ws = torch.full((B * (S + 1) * (T + 1),), -7.0, device=dev); ans = torch.empty(B, device=dev)
+    ws = torch.full((L.ftr_mutual_information_workspace_floats(B, S, T),), -7.0, device=dev); ans = torch.empty(B, device=dev)
     _lib.call("ftr_mutual_information_fwd_f32", _ptr(tpx), _ptr(tpy), _ptr(tbd), _ptr(ws), _ptr(ans), B, S, T, 0, st)
     torch.cuda.synchronize(); return ws, ans
 def bwd(impl, ws):
@@ -25,9 +25,10 @@ def bwd(impl, ws):
     gx = torch.full_like(tpx, -9.0); gy = torch.full_like(tpy, -9.0); ag = torch.ones(B, device=dev)
     _lib.call("ftr_mutual_information_bwd_f32", _ptr(tpx), _ptr(tpy), _ptr(tbd), _ptr(ws), None, _ptr(gx), _ptr(gy), _ptr(ag), 1, B, S, T, 0, st)
     torch.cuda.synchronize(); return gx.cpu().numpy(), gy.cpu().numpy(), ag.cpu().numpy()
-ws_d, ans_d = fwd(0); ws_m, ans_m = fwd(2)
+ws_d, ans_d = fwd(0); ws_m, ans_m = fwd(2)  # 0 = default (chain), 2 = mono
 print("boundary", bd.tolist()); print("ans duo", ans_d.tolist(), "mono", ans_m.tolist())
-Gd = ws_d.cpu().numpy().reshape(B, S + 1, T + 1); Gm = ws_m.cpu().numpy().reshape(B, S + 1, T + 1)
+nL = B * (S + 1) * (T + 1)
+Gd = ws_d.cpu().numpy()[:nL].reshape(B, S + 1, T + 1); Gm = ws_m.cpu().numpy()[:nL].reshape(B, S + 1, T + 1)
 print("max |G duo - G mono|", np.abs(Gd - Gm).max())
 if np.abs(Gd - Gm).max() > 1e-6:
     bad = np.argwhere(np.abs(Gd - Gm) > 1e-6); print("first differing cells", bad[:20].tolist())

@@ -12,11 +12,11 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import max_rel, random_lattice
+from helpers import assert_parity, max_rel, random_lattice
 
 pytestmark = pytest.mark.gpu
 
-IMPLS = {"wavefront": 0, "plain": 1, "mono": 2}
+IMPLS = {"wavefront": 0, "plain": 1, "mono": 2, "duo": 3}
 
 
 def _run(ft, dev, px, py, bd, impl, need_grads=True):
@@ -40,12 +40,14 @@ def test_selftest(ft, dev):
     assert int(scratch[0].item()) == 1
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono", "duo"])
 @pytest.mark.parametrize("modified", [False, True])
 @pytest.mark.parametrize("shape", [(2, 4, 8), (3, 1, 1), (3, 7, 10), (4, 50, 200), (2, 63, 70), (2, 64, 65),
-                                   (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40), (2, 383, 150), (2, 400, 130)])
+                                   (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40), (2, 383, 150), (2, 400, 130), (1, 1100, 70)])
 def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
     B, S, T = shape
+    if (impl == "duo" and S + 1 > 384) or (impl in ("mono", "plain") and S + 1 > 1024):
+        pytest.skip("family does not cover this many rows")
     px, py, bd = random_lattice(100 + S + T, B, S, T, modified=modified, ragged=True)
     ans, gx, gy, chk = _run(ft, dev, px, py, bd, impl)
     o_ans, o_p = oracle.mi_forward(px, py, bd)
@@ -55,7 +57,12 @@ def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
     # the reference propagates its seed through unreachable cells with term = exp(0) there.  Compare the rest.
     ok = np.isfinite(o_ans)
     assert not np.isnan(gx).any() and not np.isnan(gy).any()
-    assert max_rel(gx[ok], o_gx[ok]) <= 1e-4 and max_rel(gy[ok], o_gy[ok]) <= 1e-4, (max_rel(gx[ok], o_gx[ok]), max_rel(gy[ok], o_gy[ok]))
+    if max(max_rel(gx[ok], o_gx[ok]), max_rel(gy[ok], o_gy[ok])) > 1e-4:
+        # long lattice: float32 log-domain noise regime, see the module docstring -> float64 leg of the rule
+        a64, p64 = oracle.mi_forward(px, py, bd, dtype=np.float64)
+        gx64, gy64, _ = oracle.mi_backward(px, py, bd, p64, dtype=np.float64)
+        assert_parity(gx[ok], o_gx[ok], gx64[ok].astype(np.float32), what="px_grad")
+        assert_parity(gy[ok], o_gy[ok], gy64[ok].astype(np.float32), what="py_grad")
     # the reference's self-check (mutual_information_cuda.cu:510-514): recomputed ans_grad == seed
     nonempty = (bd[:, 2] >= bd[:, 0]) & (bd[:, 3] >= bd[:, 1]) & ok
     np.testing.assert_allclose(chk[nonempty], 1.0, rtol=2e-4)
@@ -157,7 +164,7 @@ def test_mi_full_size_properties(ft, dev):
     bd[1, 2] = 77; bd[1, 3] = 513; bd[2, 2] = 199; bd[2, 3] = 999
     px = px.scatter(2, bd[:, 3].long().reshape(B, 1, 1).expand(B, S, 1), float("-inf"))
     outs = {}
-    for impl in ("wavefront", "plain", "mono"):
+    for impl in ("wavefront", "plain", "mono", "duo"):
         outs[impl] = _run(ft, dev, px.numpy(), py.numpy(), bd.numpy(), impl)
     for impl, (ans, gx, gy, chk) in outs.items():
         tol = 1e-2 if impl == "plain" else 1e-4     # plain = reference arithmetic: its normalisation drifts (3e-3 here)
@@ -167,8 +174,9 @@ def test_mi_full_size_properties(ft, dev):
             np.testing.assert_allclose(gx[b, :se, :te + 1].sum(axis=1), 1.0, rtol=tol)
         np.testing.assert_allclose(chk, 1.0, rtol=tol)
     np.testing.assert_allclose(outs["wavefront"][0], outs["plain"][0], rtol=1e-5)
-    np.testing.assert_allclose(outs["wavefront"][0], outs["mono"][0], rtol=1e-6)
-    assert max_rel(outs["wavefront"][1], outs["mono"][1]) <= 1e-5 and max_rel(outs["wavefront"][2], outs["mono"][2]) <= 1e-5
+    for other in ("mono", "duo"):   # same arithmetic, different work distribution
+        np.testing.assert_allclose(outs["wavefront"][0], outs[other][0], rtol=1e-6)
+        assert max_rel(outs["wavefront"][1], outs[other][1]) <= 1e-5 and max_rel(outs["wavefront"][2], outs[other][2]) <= 1e-5
     # plain = the reference arithmetic, whose float32 noise at this size is ~7e-3
     assert max_rel(outs["wavefront"][1], outs["plain"][1]) <= 2e-2
     assert max_rel(outs["wavefront"][2], outs["plain"][2]) <= 2e-2

@@ -23,7 +23,7 @@ int device_ok() {
 int mi_impl() {
   if (g_mi_impl < 0) {
     const char* e = getenv("FTR_MI_IMPL");
-    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : (e && strcmp(e, "mono") == 0) ? 2 : 0;
+    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : (e && strcmp(e, "mono") == 0) ? 2 : (e && strcmp(e, "duo") == 0) ? 3 : 0;
   }
   return g_mi_impl;
 }
@@ -56,14 +56,15 @@ const char* ftr_last_error(void) { return g_err; }
 
 int ftr_set_mi_impl(int impl) {
   const int prev = mi_impl();
-  g_mi_impl = (impl == 1 || impl == 2) ? impl : 0;
+  g_mi_impl = (impl >= 1 && impl <= 3) ? impl : 0;
   return prev;
 }
 int ftr_get_mi_impl(void) { return mi_impl(); }
 
 size_t ftr_mutual_information_workspace_floats(int B, int S, int T) {
   if (B < 0 || S < 0 || T < 0) return 0;
-  return (size_t)B * (size_t)(S + 1) * (size_t)(T + 1);
+  // G lattice, plus the granule region of the chained wavefront kernels (mi_wave_chain.hip)
+  return (size_t)B * (size_t)(S + 1) * (size_t)(T + 1) + mi_chain_extra_floats(B, S, T);
 }
 
 int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary, float* p,
@@ -77,6 +78,7 @@ int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (mi_impl() == 1) return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
+  if (mi_impl() == 0) return mi_chain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
   return mi_wave_fwd(px, py, boundary, p, ans, B, S, T, modified, mi_impl() == 2, st);
 }
 
@@ -96,6 +98,7 @@ int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32
     FTR_REQUIRE(px && py, "mutual_information_bwd: the plain family needs px and py");
     return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
   }
+  if (mi_impl() == 0) return mi_chain_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
   return mi_wave_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, mi_impl() == 2, st);
 }
 
@@ -134,6 +137,17 @@ int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, 
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   return do_pruning(am, lm, ranges, am_pruned, lm_pruned, B, T, S1, C, r, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_do_pruning_bwd_f32(const float* g_am_pruned, const float* g_lm_pruned, const int32_t* ranges, float* d_am,
+                           float* d_lm, int B, int T, int S1, int C, int r, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 0 && S1 >= 1 && C >= 0 && r >= 0, "do_pruning_bwd: bad sizes");
+  if ((size_t)B * C == 0) return FTR_OK;
+  FTR_REQUIRE(g_am_pruned && g_lm_pruned && ranges && d_am && d_lm, "do_pruning_bwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return do_pruning_bwd(g_am_pruned, g_lm_pruned, ranges, d_am, d_lm, B, T, S1, C, r, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_pruned_logprobs_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,

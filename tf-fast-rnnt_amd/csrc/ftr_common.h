@@ -52,9 +52,13 @@ int mi_plain_fwd(const float* px, const float* py, const int32_t* boundary, floa
 int mi_plain_bwd(const float* px, const float* py, const int32_t* boundary, const float* p, float* p_grad, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
 int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, int force_mono, hipStream_t st);
 int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, int force_mono, hipStream_t st);
+int mi_chain_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
+int mi_chain_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
+size_t mi_chain_extra_floats(int B, int S, int T);
 int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st);
 int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boundary, int32_t* ranges, int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st);
 int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1, int C, int r, hipStream_t st);
+int do_pruning_bwd(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B, int T, int S1, int C, int r, hipStream_t st);
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, const float* scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int simple_rowmax_exp(const float* x, float* probs, float* rowmax, size_t rows, int C, hipStream_t st);

@@ -135,7 +135,116 @@ __global__ void do_pruning_kernel(const float* __restrict__ am, const float* __r
   }
 }
 
+// ---- backward of the prune gather (what TF autodiff does for rnnt_loss.py:802-811: a reduce_sum over the
+// broadcast axis for am, an unsorted-segment-sum for the gather of lm).
+// d am[b,t,:] = sum_k g_am_p[b,t,k,:]: one thread per 16 bytes of d am.
+template <bool VEC>
+__global__ void do_pruning_bwd_am_kernel(const float* __restrict__ g_am_p, float* __restrict__ d_am, int C, int r,
+                                         size_t total) {
+  const int per_row = VEC ? (C >> 2) : C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bt = i / per_row;
+    const int c = (int)(i - bt * per_row);
+    if (VEC) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < r; ++k) acc += reinterpret_cast<const f4u*>(g_am_p + (bt * r + k) * C)[c];
+      reinterpret_cast<f4u*>(d_am + bt * C)[c] = acc;
+    } else {
+      float acc = 0.f;
+      for (int k = 0; k < r; ++k) acc += g_am_p[(bt * r + k) * C + c];
+      d_am[bt * C + c] = acc;
+    }
+  }
+}
+
+// d lm[b,s,:] = sum over (t,k) with ranges[b,t,k] == s of g_lm_p[b,t,k,:], in increasing (t,k) order.
+// One WAVE per (b,s): pass 1 lists the matching rows in LDS with wave ballots (ordered, no barrier), pass 2
+// sums them 16 bytes per lane -- deterministic, no atomics, arbitrary `ranges` (not only the monotone bands
+// get_rnnt_prune_ranges produces).
+template <bool VEC>
+__global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges,
+                                         float* __restrict__ d_lm, int T, int S1, int C, int r) {
+  extern __shared__ int lds_list[];   // [T*r] matching row indices of this wave
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int n = T * r;
+  const int32_t* rg = ranges + (size_t)b * n;
+  const int lane = threadIdx.x;
+  int count = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // 4 candidates per lane and pass (16-byte loads where the row of `ranges` allows), list kept in index order
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(rg) & 15) == 0);
+  for (int base = 0; base < n; base += 256) {
+    const int i0 = base + 4 * lane;
+    int v[4];
+    if (vec_ok && i0 + 3 < n) {
+      const int4 q = *reinterpret_cast<const int4*>(rg + i0);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (i0 + e < n) ? rg[i0 + e] : -1;
+    }
+    bool hit[4];
+    unsigned long long m[4];
+    int before = 0, total = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hit[e] = (v[e] == s);
+      m[e] = __ballot(hit[e]);
+      before += __popcll(m[e] & lt);
+      total += __popcll(m[e]);
+    }
+    int pos = count + before;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (hit[e]) lds_list[pos++] = i0 + e;
+    count += total;
+  }
+  __syncthreads();   // one wave per block: orders the LDS list writes before the reads below
+  const float* gb = g_lm_p + (size_t)b * n * C;
+  float* out = d_lm + ((size_t)b * S1 + s) * C;
+  if (VEC) {
+    const int n4 = C >> 2;
+    for (int c = lane; c < n4; c += 64) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < count; ++j) acc += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C)[c];
+      reinterpret_cast<f4u*>(out)[c] = acc;
+    }
+  } else {
+    for (int c = lane; c < C; c += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < count; ++j) acc += gb[(size_t)lds_list[j] * C + c];
+      out[c] = acc;
+    }
+  }
+}
+
 }  // namespace
+
+int do_pruning_bwd(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B,
+                   int T, int S1, int C, int r, hipStream_t st) {
+  if ((size_t)B * T * C == 0) return FTR_OK;
+  const int threads = 256;
+  if ((C & 3) == 0) {
+    const size_t total = (size_t)B * T * (C >> 2);
+    hipLaunchKernelGGL(do_pruning_bwd_am_kernel<true>, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, st, g_am_p, d_am, C, r, total);
+  } else {
+    const size_t total = (size_t)B * T * C;
+    hipLaunchKernelGGL(do_pruning_bwd_am_kernel<false>, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, st, g_am_p, d_am, C, r, total);
+  }
+  int rc = check_launch("do_pruning_bwd_am");
+  if (rc != FTR_OK) return rc;
+  const size_t lds = sizeof(int) * (size_t)T * r;   // worst case: every (t,k) selects the same row
+  if (lds > 150 * 1024) { set_error("do_pruning_bwd: T*s_range = %d too large for the LDS row list", T * r); return FTR_ERR_UNSUPPORTED; }
+  const bool vec = (C & 3) == 0;
+  if (lds > 64 * 1024) {
+    hipError_t e = vec ? hipFuncSetAttribute(reinterpret_cast<const void*>(do_pruning_bwd_lm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                       : hipFuncSetAttribute(reinterpret_cast<const void*>(do_pruning_bwd_lm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("do_pruning_bwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FTR_ERR_LAUNCH; }
+  }
+  if (vec) hipLaunchKernelGGL(do_pruning_bwd_lm_kernel<true>, dim3(S1, B), dim3(64), lds, st, g_lm_p, ranges, d_lm, T, S1, C, r);
+  else hipLaunchKernelGGL(do_pruning_bwd_lm_kernel<false>, dim3(S1, B), dim3(64), lds, st, g_lm_p, ranges, d_lm, T, S1, C, r);
+  return check_launch("do_pruning_bwd_lm");
+}
 
 int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st) {
   if (rows == 0 || cols == 0) return FTR_OK;

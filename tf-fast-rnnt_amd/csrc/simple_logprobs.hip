@@ -78,10 +78,26 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   const int T1 = MOD ? T : T + 1;
   const int ld = C + 1;
   const float* amb = am + (size_t)b * T * C;
-  // stage TT frames of am (zeros past T), coalesced along c
-  for (int i = threadIdx.x; i < TT * C; i += blockDim.x) {
-    const int tt = i / C, c = i - tt * C;
-    tile[tt * ld + c] = (t0 + tt < T) ? amb[(size_t)(t0 + tt) * C + c] : 0.0f;
+  // stage TT frames of am (zeros past T): two rows per pass, 16 bytes per lane along c where C allows
+  {
+    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
+    if ((C & 3) == 0) {
+      const int n4 = C >> 2;
+      for (int tt = half; tt < TT; tt += 2) {
+        const bool ok = t0 + tt < T;
+        const f4u* src = reinterpret_cast<const f4u*>(amb + (size_t)(t0 + tt) * C);
+        for (int c4 = cl; c4 < n4; c4 += 128) {
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) v = src[c4];
+          float* dst = tile + tt * ld + 4 * c4;
+          dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+      }
+    } else {
+      for (int tt = half; tt < TT; tt += 2)
+        for (int c = cl; c < C; c += 128)
+          tile[tt * ld + c] = (t0 + tt < T) ? amb[(size_t)(t0 + tt) * C + c] : 0.0f;
+    }
   }
   __syncthreads();
   const int tx = threadIdx.x & (TT - 1);
@@ -175,19 +191,36 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
     if (tok) cs += gpy[((size_t)b * (S + 1) + s) * T + t];
   csy[ty * TT + tx] = cs;
   __syncthreads();
-  // write-out, coalesced along c
-  for (int i = threadIdx.x; i < TT * C; i += blockDim.x) {
-    const int tt = i / C, c = i - tt * C;
-    if (t0 + tt < T) {
-      const size_t o = ((size_t)b * T + t0 + tt) * C + c;
-      float v = damp[o] * am_probs[o] + acc[tt * ld + c];
-      if (c == blank) {
-        float col = 0.0f;
+  // write-out: two frames per pass, 16 bytes per lane along c where C allows
+  {
+    const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
+    for (int tt = half; tt < TT; tt += 2) {
+      if (t0 + tt >= T) continue;
+      float col = 0.0f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) col += csy[g * TT + tt];
-        v += col;
+      for (int g = 0; g < 8; ++g) col += csy[g * TT + tt];
+      const size_t o = ((size_t)b * T + t0 + tt) * C;
+      const float* arow = acc + tt * ld;
+      if ((C & 3) == 0) {
+        const int n4 = C >> 2;
+        for (int c4 = cl; c4 < n4; c4 += 128) {
+          const f4 dp = reinterpret_cast<const f4u*>(damp + o)[c4];
+          const f4 ap = reinterpret_cast<const f4u*>(am_probs + o)[c4];
+          f4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = dp[e] * ap[e] + arow[4 * c4 + e];
+            if (4 * c4 + e == blank) v[e] += col;
+          }
+          reinterpret_cast<f4u*>(d_am + o)[c4] = v;
+        }
+      } else {
+        for (int c = cl; c < C; c += 128) {
+          float v = damp[o + c] * am_probs[o + c] + arow[c];
+          if (c == blank) v += col;
+          d_am[o + c] = v;
+        }
       }
-      d_am[o] = v;
     }
   }
 }

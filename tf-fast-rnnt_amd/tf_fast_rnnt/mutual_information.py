@@ -84,7 +84,7 @@ def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[t
         ag = torch.ones((B,), dtype=torch.float32, device=px.device) if ans_grad is None else ans_grad.to(torch.float32).contiguous().clone()
         p_grad = None
         if L.ftr_get_mi_impl() == 1:   # the plain family follows the reference and materialises p_grad
-            p_grad = torch.empty_like(ws)
+            p_grad = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=px.device)
         _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), _ptr(p_grad),
                                                     _ptr(px_grad), _ptr(py_grad), _ptr(ag), 1, B, S, T, modified, st)
     return (ans, px_grad, py_grad, ag) if return_ans_grad_check else (ans, px_grad, py_grad)

@@ -357,10 +357,13 @@ class _DoPruning(torch.autograd.Function):
     def backward(ctx, g_am_p, g_lm_p):
         (ranges,) = ctx.saved_tensors
         B, S1, C = ctx.lm_shape
-        g_am = g_am_p.sum(dim=2)                                             # broadcast  <-> sum over s_range
-        g_lm = torch.zeros((B, S1, C), dtype=g_lm_p.dtype, device=g_lm_p.device)
-        idx = _i64(ranges).reshape(B, -1, 1).expand(B, ranges.shape[1] * ranges.shape[2], C)
-        g_lm.scatter_add_(1, idx, g_lm_p.reshape(B, -1, C))                   # gather     <-> scatter-add
+        T, r = ranges.shape[1], ranges.shape[2]
+        g_am_p = g_am_p.contiguous(); g_lm_p = g_lm_p.contiguous()
+        g_am = torch.empty((B, T, C), dtype=g_am_p.dtype, device=g_am_p.device)     # broadcast <-> sum over s_range
+        g_lm = torch.empty((B, S1, C), dtype=g_lm_p.dtype, device=g_lm_p.device)    # gather    <-> segment sum
+        with torch.cuda.device(g_am_p.device):
+            _lib.call("ftr_do_pruning_bwd_f32", _ptr(g_am_p), _ptr(g_lm_p), _ptr(ranges), _ptr(g_am), _ptr(g_lm),
+                      B, T, S1, C, r, _stream_ptr(g_am_p))
         return g_am, g_lm, None
 
 
