@@ -60,14 +60,22 @@ def make_inputs(B, T, S, C, seed, device, ragged=False):
     return dict(am=am, lm=lm, symbols=symbols, boundary=boundary.to(device), blank=C - 1, B=B, T=T, S=S, C=C)
 
 
-def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5):
-    """One full step of the hot path (see module docstring).  Returns the scalar loss (and internals)."""
+def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5, first_pass="simple", process_group=None):
+    """One full step of the hot path (see module docstring).  Returns the scalar loss (and internals).
+    first_pass = "smoothed" uses rnnt_loss_smoothed (lm_only_scale 0.1, am_only_scale 0.2 as in
+    simple_rnnt_loss_test.py:291-336) for the occupancy pass (BASELINE.json configs[3], "c4")."""
     import tf_fast_rnnt as ft
     am = inp["am"].detach().requires_grad_(True)
     lm = inp["lm"].detach().requires_grad_(True)
     sym, bd, blank = inp["symbols"], inp["boundary"], inp["blank"]
-    simple_loss, (px_grad, py_grad) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank,
-                                                         boundary=bd, reduction="sum", calc_gradients=True)
+    if first_pass == "smoothed":
+        simple_loss, (px_grad, py_grad) = ft.rnnt_loss_smoothed(lm=lm, am=am, symbols=sym, termination_symbol=blank,
+                                                               lm_only_scale=0.1, am_only_scale=0.2, boundary=bd,
+                                                               reduction="sum", calc_gradients=True,
+                                                               process_group=process_group)
+    else:
+        simple_loss, (px_grad, py_grad) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank,
+                                                             boundary=bd, reduction="sum", calc_gradients=True)
     ranges = ft.get_rnnt_prune_ranges(px_grad=px_grad, py_grad=py_grad, boundary=bd, s_range=s_range)
     am_p, lm_p = ft.do_rnnt_pruning(am=am, lm=lm, ranges=ranges)
     logits = torch.sigmoid(am_p + lm_p)
@@ -116,12 +124,60 @@ class CallTimer:
         return out
 
 
+# native call -> the kernels it launches (names as rocprofv3 prints them, namespace stripped), for the PMC traffic
+CALL_KERNELS = {
+    "ftr_mutual_information_fwd_f32": ["mi_chain_fwd_kernel<false>"],
+    "ftr_mutual_information_bwd_f32": ["mi_chain_bwd_kernel<false>"],
+    "ftr_prune_ranges_i32": ["prune_argmax_kernel", "prune_adjust_kernel"],
+    "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
+    "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
+    "ftr_pruned_logprobs_fwd_f32": ["lse_rows_kernel<true>", "band_to_lattice_kernel<false>"],
+    "ftr_pruned_logprobs_bwd_f32": ["band_grad_kernel<false, true>"],
+    "ftr_rowmax_exp_f32": ["rowmax_exp_kernel<true>"],
+    "ftr_simple_logprobs_fwd_f32": ["simple_fwd_kernel<false>"],
+    "ftr_simple_logprobs_bwd_w_f32": ["simple_bwd_w_kernel<false>"],
+    "ftr_simple_logprobs_bwd_am_f32": ["simple_bwd_am_kernel<false>"],
+    "ftr_simple_logprobs_bwd_lm_f32": ["simple_bwd_lm_kernel"],
+}
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/r*_pmc_traffic.json,
+    made by scripts/summarize_pmc.py: FETCH_SIZE and WRITE_SIZE in separate runs, KiB units, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950).  Counters cannot be read from inside the timed process, so the bench
+    line carries the last committed measurement and names its file; None if there is none for this config."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{config}.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        per_kernel = json.load(f)
+    out = {}
+    for call, kernels in CALL_KERNELS.items():
+        if all(k in per_kernel for k in kernels):
+            out[call] = sum(per_kernel[k]["hbm_bytes"] for k in kernels)
+    return out, os.path.relpath(files[-1], ROOT)
+
+
 def algorithmic_bytes(B, T, S, C, r):
     """SURVEY.md 8(d) algorithmic bytes per native call (f32 = 4 B).  L = lattice cells."""
     L = B * (S + 1) * (T + 1)
     npx, npy = B * S * (T + 1), B * (S + 1) * T
     N = 4 * B * T * r * C
+    nam, nlm = B * T * C, B * (S + 1) * C
     return {
+        # simple/smoothed builder (SURVEY.md 8d: "report bytes and flops separately; it is not the headline")
+        "ftr_rowmax_exp_f32": 4 * (nam + nlm),                              # mean of the am call and the lm call: read + write
+        "ftr_rowmax_exp_sum_f32": 4 * 2 * nlm,
+        "ftr_simple_logprobs_fwd_f32": 4 * (nam + nlm + npy + npx + npy),   # read am, lm, prod; write px, py
+        "ftr_smoothed_logprobs_fwd_f32": 4 * (nam + nlm + npy + npx + npy),
+        "ftr_simple_logprobs_bwd_w_f32": 4 * (npx + 3 * npy),               # read gpx, gpy, prod; write W
+        "ftr_smoothed_logprobs_bwd_w_f32": 4 * (npx + 3 * npy),
+        "ftr_simple_logprobs_bwd_am_f32": 4 * (npx + npy + 3 * nam),        # read gpx, gpy, damp, am_probs; write d am
+        "ftr_smoothed_logprobs_bwd_am_f32": 4 * (npx + npy + 3 * nam),
+        "ftr_simple_logprobs_bwd_lm_f32": 4 * 3 * nlm,
+        "ftr_smoothed_logprobs_bwd_lm_f32": 4 * 3 * nlm,
+        "ftr_do_pruning_bwd_f32": 2 * N + 4 * (nam + nlm + B * T * r),      # read both pruned gradients, write d am, d lm
         # fwd reads px,py and writes p; bwd (reference algorithm) reads px,py,p and writes both grads: 32 L total
         "ftr_mutual_information_fwd_f32": 4 * (npx + npy + L),
         "ftr_mutual_information_bwd_f32": 4 * (npx + npy + L + npx + npy),
@@ -179,6 +235,8 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--first-pass", default=None, choices=["simple", "smoothed"],
+                    help="occupancy pass; default simple, smoothed for c4 (BASELINE.json configs[3])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,8 +258,11 @@ def main():
     B, T, S, C, r = CONFIGS[args.config]
     inp = make_inputs(B, T, S, C, seed=1000 + rank, device=dev, ragged=args.ragged)
 
+    first_pass = args.first_pass or ("smoothed" if args.config == "c4" else "simple")
+    group = dist.group.WORLD if (dist is not None and first_pass == "smoothed") else None
+
     def step():
-        loss = pruned_step(inp, r)
+        loss = pruned_step(inp, r, first_pass=first_pass, process_group=group)
         if dist is not None:
             dist.all_reduce(loss)           # the single scalar exchange of the sharded loss
         return loss
@@ -248,11 +309,19 @@ def main():
     # dominant native call of the step = largest total time
     dom = max(calls, key=lambda n: calls[n]["total_ms"]) if calls else None
     roofline = None
+    traffic, traffic_file = pmc_traffic(args.config) if (first_pass == "simple" and not args.ragged) else (None, None)
+    if traffic:
+        for name in kernels:
+            kernels[name]["pmc_hbm_MB"] = round(traffic[name] / 1e6, 1) if name in traffic else None
     if dom is not None and dom in alg:
         achieved = alg[dom] / (calls[dom]["avg_us"] * 1e-6) / 1e9
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=(traffic or {}).get(dom), traffic_source=traffic_file,
                         avg_launch_us=round(calls[dom]["avg_us"], 2), algorithmic_bytes=alg[dom])
+    # the streaming share of the step against the same roofline: all native calls together
+    tot_alg = sum(alg[n] * calls[n]["calls"] for n in calls if n in alg) / args.steps
+    tot_us = sum(calls[n]["total_ms"] for n in calls if n in alg) * 1e3 / args.steps
     native_us = sum(rec["total_ms"] for rec in calls.values()) * 1e3 / args.steps
     out = {
         "metric": "rnnt_loss_pruned_fwd_bwd_throughput",
@@ -270,10 +339,13 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.config}: rnnt_loss_pruned fwd+bwd step, B={B}/GPU T={T} S={S} C={C} s_range={r}, "
-                               f"regular, {'ragged' if args.ragged else 'full'} boundary",
+                               f"regular, {'ragged' if args.ragged else 'full'} boundary, first pass rnnt_loss_{first_pass}",
                    "global_batch": world * B, "sharding": f"batch x{world}, one scalar all-reduce/step"},
         "roofline": roofline,
         "native_us_per_step": round(native_us, 1),
+        "native_aggregate": {"algorithmic_MB_per_step": round(tot_alg / 1e6, 1), "us_per_step": round(tot_us, 1),
+                             "GBps": round(tot_alg / (tot_us * 1e-6) / 1e9, 1) if tot_us > 0 else None,
+                             "frac_of_peak": round(tot_alg / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tot_us > 0 else None},
         "kernels": kernels,
         "loss": float(last.item()),
     }

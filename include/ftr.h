@@ -168,6 +168,41 @@ int ftr_simple_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, con
                                    const float* rsx, const float* rsy, int termination_symbol, float* d_lm, int B,
                                    int S, int C, void* stream);
 
+/*
+ * Smoothed px/py builder.  Replaces get_rnnt_logprobs_smoothed (rnnt_loss.py:1132-1367) and its autodiff: the
+ * same kernels as above with the LM-only and AM-only interpolation terms (rnnt_loss.py:1342-1360) folded in,
+ *   out = combined_scale (x - normalizers) + lm_only_scale (lm - lmonly_norm[b,s])
+ *         + am_only_scale (am + unigram_log[c] - amonly_norm[b,t]).
+ * The batch statistics are small vectors the host prepares between calls (rnnt_loss.py:1276-1290):
+ *   lmonly_norm [B,S+1] = log(rowsum lm_probs) + lm_max   (ftr_rowmax_exp_sum_f32 also returns the row sums)
+ *   unigram [C] = mean_{b,s} lm_probs/rowsum + tiny; unigram_log = log unigram
+ *   am_dot [B,T] = am_probs . unigram;  amonly_norm = log am_dot + am_max
+ * Backward: W carries combined_scale; bwd_am adds direct_scale (= combined + am_only) on the scattered terms and
+ * am_probs * unigram * R with R[b,t] = -am_only_scale * colsum(gpx' + gpy) / am_dot (R is written out, it feeds
+ * d unigram); bwd_lm adds direct_scale (= combined + lm_only) and lm_probs * (row_term[b,s] +
+ * unigram_grad[c] * inv_rowsum[b,s]).  Zero scales must already be replaced by 1e-20 (rnnt_loss.py:1346-1349).
+ */
+int ftr_rowmax_exp_sum_f32(const float* x, float* probs, float* rowmax, float* rowsum, long long rows, int C,
+                           void* stream);
+int ftr_smoothed_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                                  const float* am_max, const float* lm_max, const float* lmonly_norm,
+                                  const float* amonly_norm, const float* unigram_log, const int32_t* boundary,
+                                  int termination_symbol, float combined_scale, float lm_only_scale,
+                                  float am_only_scale, float* px, float* py, int B, int T, int S, int C,
+                                  int modified, void* stream);
+int ftr_smoothed_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
+                                    float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,
+                                    int modified, void* stream);
+int ftr_smoothed_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
+                                     const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                     float direct_scale, const float* unigram, const float* am_dot,
+                                     float am_only_scale, float* R, float* d_am, int B, int T, int S, int C,
+                                     int modified, void* stream);
+int ftr_smoothed_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, const int32_t* symbols,
+                                     const float* rsx, const float* rsy, int termination_symbol, float direct_scale,
+                                     const float* row_term, const float* inv_rowsum, const float* unigram_grad,
+                                     float* d_lm, int B, int S, int C, void* stream);
+
 /* Hardware self-test used by smoke()/tests: checks on the device that the primitives the wavefront
  * kernels rely on behave as assumed (full-wave DPP shift wave_shr:1 with lane 0 keeping its old value;
  * 16-byte global loads/stores at 4-byte alignment).  scratch_dev: >= 8 KiB of device memory; after the

@@ -235,3 +235,98 @@ def test_native_simple_builder_odd_vocab_and_penalty(ft, dev, oracle):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ft.get_rnnt_logprobs(_t(d["lm"], "cpu"), _t(d["am"], "cpu"), _t(d["symbols"], "cpu"), d["termination_symbol"])
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
+@pytest.mark.parametrize("scales", [(0.1, 0.2), (0.0, 0.0), (0.25, 0.0)])
+@pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7)])
+def test_native_smoothed_builder_forward_backward(ft, dev, oracle, rnnt_type, scales, cfg):
+    """get_rnnt_logprobs_smoothed on the native builder kernels (rnnt_loss.py:1132-1367): px/py against the oracle
+    with the exact -inf pattern (tolerance 2e-5 absolute/relative: f32 sums in a different order); d/d am and d/d lm
+    against float64 autograd through the op-by-op torch restatement, 1e-4 normwise."""
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_smoothed_torch
+    B, T, S, C = cfg
+    d = synthetic(21, B, T, S, C, ragged=True)
+    am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+    sym = _t(d["symbols"], dev); bd = _t(d["boundary"], dev)
+    px, py = ft.get_rnnt_logprobs_smoothed(lm, am, sym, d["termination_symbol"], scales[0], scales[1], bd, rnnt_type)
+    o_px, o_py = oracle.get_rnnt_logprobs_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"],
+                                                   scales[0], scales[1], d["boundary"], rnnt_type)
+    pxn = px.detach().cpu().numpy(); pyn = py.detach().cpu().numpy()
+    assert pxn.shape == o_px.shape and pyn.shape == o_py.shape
+    assert np.array_equal(np.isneginf(pxn), np.isneginf(o_px))
+    fin = np.isfinite(o_px)
+    np.testing.assert_allclose(pxn[fin], o_px[fin], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(pyn, o_py, rtol=2e-5, atol=2e-5)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    wx = torch.randn(px.shape, generator=g).to(dev); wy = torch.randn(py.shape, generator=g).to(dev)
+    finite = torch.isfinite(px.detach())
+    (torch.where(finite, px, torch.zeros_like(px)) * wx).sum().add((py * wy).sum()).backward()
+    am64 = am.detach().double().requires_grad_(True); lm64 = lm.detach().double().requires_grad_(True)
+    px64, py64 = _get_rnnt_logprobs_smoothed_torch(lm64, am64, sym, d["termination_symbol"], scales[0], scales[1], bd,
+                                                   rnnt_type)
+    (torch.where(finite, px64, torch.zeros_like(px64)) * wx.double()).sum().add((py64 * wy.double()).sum()).backward()
+    assert max_rel(am.grad.cpu().numpy(), am64.grad.cpu().numpy()) <= 1e-4
+    assert max_rel(lm.grad.cpu().numpy(), lm64.grad.cpu().numpy()) <= 1e-4
+
+
+def test_smoothed_loss_against_oracle(ft, dev, oracle):
+    """rnnt_loss_smoothed end to end (simple_rnnt_loss_test.py:291-336 scales and penalty): loss and occupancies."""
+    d = reference_test_recipe(12345, 2, 200, 50, 50)
+    args = (_t(d["lm"], dev), _t(d["am"], dev), _t(d["symbols"], dev), d["termination_symbol"])
+    for rt in ("regular", "modified"):
+        got, (gx, gy) = ft.rnnt_loss_smoothed(*args, lm_only_scale=0.1, am_only_scale=0.2, boundary=_t(d["boundary"], dev),
+                                              rnnt_type=rt, delay_penalty=0.2, reduction="none", calc_gradients=True)
+        want, (ox, oy) = oracle.rnnt_loss_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"], 0.1, 0.2,
+                                                   d["boundary"], rt, 0.2, "none", True)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4)
+        assert max_rel(gx.cpu().numpy(), ox) <= 5e-4 and max_rel(gy.cpu().numpy(), oy) <= 5e-4
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
+def test_native_joint_builder_and_unpruned_loss(ft, dev, oracle, rnnt_type):
+    """get_rnnt_logprobs_joint / rnnt_loss (rnnt_loss.py:340-551) on the pruned builder's kernels with identity ranges:
+    px/py against the oracle, loss against the oracle, d/d logits against float64 autograd of the torch restatement."""
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_joint_torch
+    d = synthetic(31, 2, 21, 6, 9, ragged=True)
+    logits_np = (d["am"][:, :, None, :] + d["lm"][:, None, :, :]).astype(np.float32)
+    logits = _t(logits_np, dev).requires_grad_(True)
+    sym = _t(d["symbols"], dev); bd = _t(d["boundary"], dev); blank = d["termination_symbol"]
+    px, py = ft.get_rnnt_logprobs_joint(logits, sym, blank, bd, rnnt_type)
+    o_px, o_py = oracle.get_rnnt_logprobs_joint(logits_np, d["symbols"], blank, d["boundary"], rnnt_type)
+    pxn = px.detach().cpu().numpy()
+    assert np.array_equal(np.isneginf(pxn), np.isneginf(o_px))
+    fin = np.isfinite(o_px)
+    np.testing.assert_allclose(pxn[fin], o_px[fin], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(py.detach().cpu().numpy(), o_py, rtol=1e-5, atol=2e-5)
+    loss = ft.rnnt_loss(logits, sym, blank, bd, rnnt_type, delay_penalty=0.1, reduction="sum")
+    want = oracle.rnnt_loss(logits_np, d["symbols"], blank, d["boundary"], rnnt_type, 0.1, "sum")
+    np.testing.assert_allclose(loss.item(), want, rtol=1e-4)
+    loss.backward()
+    l64 = logits.detach().double().requires_grad_(True)
+    px64, py64 = _get_rnnt_logprobs_joint_torch(l64, sym, blank, bd, rnnt_type)
+    from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty
+    px64 = _apply_delay_penalty(px64, bd, rnnt_type, 0.1)
+    # float64 DP in torch (log-domain, autograd) as the gradient reference
+    B, S, T1 = px64.shape; T = py64.shape[2]
+    tot = 0.0
+    for b in range(B):
+        sb, tb, se, te = [int(v) for v in d["boundary"][b]]
+        p = {}
+        for s in range(sb, se + 1):
+            for t in range(tb, te + 1):
+                if s == sb and t == tb:
+                    p[(s, t)] = px64.new_zeros(()); continue
+                terms = []
+                if s > sb:
+                    tt = t if rnnt_type == "regular" else t - 1
+                    if tt >= tb and (s - 1, tt) in p and torch.isfinite(px64[b, s - 1, tt]):
+                        terms.append(p[(s - 1, tt)] + px64[b, s - 1, tt])
+                if t > tb and (s, t - 1) in p:
+                    terms.append(p[(s, t - 1)] + py64[b, s, t - 1])
+                if terms:
+                    p[(s, t)] = torch.logsumexp(torch.stack(terms), 0)
+        tot = tot - p[(se, te)]
+    tot.backward()
+    assert abs(tot.item() - loss.item()) <= 1e-4 * abs(tot.item())
+    assert max_rel(logits.grad.cpu().numpy(), l64.grad.cpu().numpy()) <= 1e-4

@@ -33,8 +33,9 @@ def test_get_rnnt_logprobs_torch_restatement(ft, oracle, rnnt_type):
 @pytest.mark.parametrize("scales", [(0.1, 0.2), (0.0, 0.0), (0.25, 0.0)])
 def test_get_rnnt_logprobs_smoothed(ft, oracle, rnnt_type, scales):
     d = reference_test_recipe(1234, 2, 10, 7, 4)
-    px, py = ft.get_rnnt_logprobs_smoothed(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"],
-                                           scales[0], scales[1], _t(d["boundary"]), rnnt_type)
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_smoothed_torch   # host restatement (autograd oracle on GPU)
+    px, py = _get_rnnt_logprobs_smoothed_torch(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"],
+                                               scales[0], scales[1], _t(d["boundary"]), rnnt_type)
     o_px, o_py = oracle.get_rnnt_logprobs_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"],
                                                    scales[0], scales[1], d["boundary"], rnnt_type)
     assert np.array_equal(np.isneginf(px.numpy()), np.isneginf(o_px))
@@ -44,10 +45,11 @@ def test_get_rnnt_logprobs_smoothed(ft, oracle, rnnt_type, scales):
 
 
 def test_get_rnnt_logprobs_joint(ft, oracle):
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_joint_torch as _joint_torch   # host restatement
     d = synthetic(1, 2, 7, 4, 6, ragged=True)
     logits = (d["am"][:, :, None, :] + d["lm"][:, None, :, :]).astype(np.float32)
     for rnnt_type in ("regular", "modified", "constrained"):
-        px, py = ft.get_rnnt_logprobs_joint(_t(logits), _t(d["symbols"]), d["termination_symbol"], _t(d["boundary"]), rnnt_type)
+        px, py = _joint_torch(_t(logits), _t(d["symbols"]), d["termination_symbol"], _t(d["boundary"]), rnnt_type)
         o_px, o_py = oracle.get_rnnt_logprobs_joint(logits, d["symbols"], d["termination_symbol"], d["boundary"], rnnt_type)
         fin = np.isfinite(o_px)
         assert np.array_equal(np.isfinite(px.numpy()), fin)
@@ -102,7 +104,7 @@ def _gloo_worker(rank, world, port, B, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tf_fast_rnnt.distributed import all_reduce_sum_differentiable, reduce_loss, shard_batch
-    from tf_fast_rnnt.rnnt_loss import get_rnnt_logprobs_smoothed
+    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_smoothed_torch as get_rnnt_logprobs_smoothed
     torch.manual_seed(0)
     full = torch.randn(B, dtype=torch.float64)            # per-utterance losses of the whole batch
     lo, hi = shard_batch(B, rank, world)

@@ -186,7 +186,18 @@ int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long ro
   FTR_REQUIRE(x && probs && rowmax, "rowmax_exp: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_rowmax_exp(x, probs, rowmax, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+  return simple_rowmax_exp(x, probs, rowmax, nullptr, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_rowmax_exp_sum_f32(const float* x, float* probs, float* rowmax, float* rowsum, long long rows, int C,
+                           void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows >= 0 && C >= 0, "rowmax_exp_sum: negative size");
+  if (rows == 0 || C == 0) return FTR_OK;
+  FTR_REQUIRE(x && probs && rowmax && rowsum, "rowmax_exp_sum: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_rowmax_exp(x, probs, rowmax, rowsum, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
@@ -200,7 +211,23 @@ int ftr_simple_logprobs_fwd_f32(const float* am, const float* lm, const int32_t*
   FTR_REQUIRE(am && lm && prod && am_max && lm_max && py && (symbols || S == 0) && (px || S == 0), "simple_logprobs_fwd: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_fwd(am, lm, symbols, prod, am_max, lm_max, boundary, termination_symbol, delay_penalty, px, py, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_fwd(am, lm, symbols, prod, am_max, lm_max, boundary, termination_symbol, delay_penalty, nullptr, nullptr, nullptr, 1.0f, 0.0f, 0.0f, px, py, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                                  const float* am_max, const float* lm_max, const float* lmonly_norm,
+                                  const float* amonly_norm, const float* unigram_log, const int32_t* boundary,
+                                  int termination_symbol, float combined_scale, float lm_only_scale,
+                                  float am_only_scale, float* px, float* py, int B, int T, int S, int C,
+                                  int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "smoothed_logprobs_fwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_fwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(am && lm && prod && am_max && lm_max && lmonly_norm && amonly_norm && unigram_log && py && (symbols || S == 0) && (px || S == 0), "smoothed_logprobs_fwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_fwd(am, lm, symbols, prod, am_max, lm_max, boundary, termination_symbol, 0.0, lmonly_norm, amonly_norm, unigram_log, combined_scale, lm_only_scale, am_only_scale, px, py, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
@@ -211,7 +238,19 @@ int ftr_simple_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const floa
   FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "simple_logprobs_bwd_w: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_w(gpx, gpy, prod, boundary, W, rsx, rsy, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_w(gpx, gpy, prod, boundary, W, rsx, rsy, 1.0f, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
+                                    float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,
+                                    int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0, "smoothed_logprobs_bwd_w: bad sizes");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "smoothed_logprobs_bwd_w: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_w(gpx, gpy, prod, boundary, W, rsx, rsy, combined_scale, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
@@ -224,7 +263,22 @@ int ftr_simple_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const flo
   FTR_REQUIRE(gpy && damp && am_probs && d_am && (gpx || S == 0) && (symbols || S == 0), "simple_logprobs_bwd_am: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_am(gpx, gpy, damp, am_probs, symbols, boundary, termination_symbol, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_am(gpx, gpy, damp, am_probs, symbols, boundary, termination_symbol, 1.0f, nullptr, nullptr, 0.0f, nullptr, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
+                                     const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                     float direct_scale, const float* unigram, const float* am_dot,
+                                     float am_only_scale, float* R, float* d_am, int B, int T, int S, int C,
+                                     int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "smoothed_logprobs_bwd_am: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_bwd_am: bad termination_symbol");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && damp && am_probs && d_am && unigram && am_dot && R && (gpx || S == 0) && (symbols || S == 0), "smoothed_logprobs_bwd_am: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_am(gpx, gpy, damp, am_probs, symbols, boundary, termination_symbol, direct_scale, unigram, am_dot, am_only_scale, R, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, const int32_t* symbols,
@@ -237,7 +291,21 @@ int ftr_simple_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, con
   FTR_REQUIRE(dlmp && lm_probs && rsx && rsy && d_lm && (symbols || S == 0), "simple_logprobs_bwd_lm: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_lm(dlmp, lm_probs, symbols, rsx, rsy, termination_symbol, d_lm, B, S, C, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_lm(dlmp, lm_probs, symbols, rsx, rsy, termination_symbol, 1.0f, nullptr, nullptr, nullptr, d_lm, B, S, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, const int32_t* symbols,
+                                     const float* rsx, const float* rsy, int termination_symbol, float direct_scale,
+                                     const float* row_term, const float* inv_rowsum, const float* unigram_grad,
+                                     float* d_lm, int B, int S, int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 0 && C >= 1, "smoothed_logprobs_bwd_lm: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_bwd_lm: bad termination_symbol");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(dlmp && lm_probs && rsx && rsy && d_lm && row_term && inv_rowsum && unigram_grad && (symbols || S == 0), "smoothed_logprobs_bwd_lm: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_lm(dlmp, lm_probs, symbols, rsx, rsy, termination_symbol, direct_scale, row_term, inv_rowsum, unigram_grad, d_lm, B, S, C, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_selftest(void* scratch_dev, void* stream) {

@@ -50,16 +50,20 @@ __device__ __forceinline__ void comm_publish(const float* out_ring, u64* gran_ou
     __hip_atomic_store(gran_out + CH * m + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-// import chunk m of the band above into the LDS in-ring; returns false after a timeout
-__device__ __forceinline__ bool comm_import(float* in_ring, const u64* gran_in, int m, int lane) {
+// import chunk m of the band above into the LDS in-ring.  `g` holds the granule this lane loaded for chunk m one
+// slot earlier (the ~1.5 us sc1 round trip is hidden behind a whole slot); only if a tag does not match yet does
+// the wave fall into the polling loop.  Returns false after a timeout.
+__device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
+  return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool comm_import(float* in_ring, const u64* gran_in, int m, int lane, u64 g) {
   const int idx = CH * m + (lane & (CH - 1));
-  u64 g = 0;
   for (int spins = 0;; ++spins) {
-    g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool ok = (unsigned)(g >> 32) == (unsigned)(m + 1);
     if (__all(ok)) break;                 // wave-uniform exit
     if (spins >= kMaxSpin) return false;  // wave-uniform (spins is uniform)
     __builtin_amdgcn_s_sleep(24);
+    g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane < CH) in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
   return true;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(192) void mi_chain_fwd_kernel(
       if (kc >= 8 && kc + 8 < nchunks) { st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += 1; }
     }
 #ifdef FTR_STAMPS
-    if (b == 0 && threadIdx.x == 0) { g_stamps[0] = st_acc[0]; g_stamps[1] = st_acc[1]; g_stamps[2] = st_acc[2]; }
+    if (b == 0 && w == 1 && threadIdx.x == 0) { g_stamps[0] = st_acc[0]; g_stamps[1] = st_acc[1]; g_stamps[2] = st_acc[2]; }
 #endif
     return;
   }
@@ -184,16 +188,20 @@ __global__ __launch_bounds__(192) void mi_chain_fwd_kernel(
     const u64* gran_in = gran + ((size_t)b * NB + w) * Tg;         // written by band w-1
     const bool has_up = w > 0, has_down = w + 1 < NWact;
     bool dead = false;
+    u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       if (has_down && kc - 1 >= 0 && kc - 1 < nchunks) comm_publish(out_ring, gran_out, kc - 1, lane);
       const int m = kc + LOOK;
+      u64 g_next = 0;
+      if (has_up && !dead && m + 1 >= 0 && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
       if (has_up && !dead && m >= 0 && m < nchunks) {
-        if (!comm_import(in_ring, gran_in, m, lane)) {   // producer never showed up: poison, stop polling
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {   // producer never showed up: poison, stop polling
           dead = true;
           in_ring[lane] = __builtin_nanf("");
         }
       }
+      g_cur = g_next;
       __syncthreads();
     }
     return;
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(192) void mi_chain_fwd_kernel(
     for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
   }
 #ifdef FTR_STAMPS
-  if (b == 0 && w == 0 && lane == 0)
+  if (b == 0 && w == 1 && lane == 0)
     for (int i = 0; i < 5; ++i) g_stamps[3 + i] = st_acc[i];
 #endif
 }
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(192) void mi_chain_bwd_kernel(
       if (kc >= 8 && kc + 8 < nchunks) { st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += 1; }
     }
 #ifdef FTR_STAMPS
-    if (b == 0 && threadIdx.x == 0) { g_stamps[8] = st_acc[0]; g_stamps[9] = st_acc[1]; g_stamps[10] = st_acc[2]; }
+    if (b == 0 && w == 1 && threadIdx.x == 0) { g_stamps[8] = st_acc[0]; g_stamps[9] = st_acc[1]; g_stamps[10] = st_acc[2]; }
 #endif
     return;
   }
@@ -534,16 +542,20 @@ __global__ __launch_bounds__(192) void mi_chain_bwd_kernel(
     const u64* gran_in = gran + ((size_t)b * NB + w) * Tg;
     const bool has_up = w > 0, has_down = w + 1 < NWact;
     bool dead = false;
+    u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       if (has_down && kc - 1 >= 0 && kc - 1 < nchunks) comm_publish(out_ring, gran_out, kc - 1, lane);
       const int m = kc + LOOK;
+      u64 g_next = 0;
+      if (has_up && !dead && m + 1 >= 0 && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
       if (has_up && !dead && m >= 0 && m < nchunks) {
-        if (!comm_import(in_ring, gran_in, m, lane)) {
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {
           dead = true;
           in_ring[lane] = __builtin_nanf("");
         }
       }
+      g_cur = g_next;
       __syncthreads();
     }
     return;
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(192) void mi_chain_bwd_kernel(
     for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
   }
 #ifdef FTR_STAMPS
-  if (b == 0 && w == 0 && lane == 0)
+  if (b == 0 && w == 1 && lane == 0)
     for (int i = 0; i < 5; ++i) g_stamps[11 + i] = st_acc[i];
 #endif
 }
@@ -759,6 +771,14 @@ int mi_chain_bwd(const int32_t* boundary, const float* ws, float* px_grad, float
   if (modified) hipLaunchKernelGGL(mi_chain_bwd_kernel<true>, dim3(B * NB), dim3(192), lds, st, boundary, ws, gran, px_grad, py_grad, ans_grad, overwrite, B, NB, Tg, S, T);
   else hipLaunchKernelGGL(mi_chain_bwd_kernel<false>, dim3(B * NB), dim3(192), lds, st, boundary, ws, gran, px_grad, py_grad, ans_grad, overwrite, B, NB, Tg, S, T);
   return check_launch("mi_chain_bwd");
+}
+
+// diagnostic (make STAMPS=1): s_memtime sums of the chain kernels' steady-state slots, band 0 of utterance 0
+int debug_stamps(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) {
+    set_error("debug_stamps: hipMemcpyFromSymbol failed"); return FTR_ERR_LAUNCH;
+  }
+  return FTR_OK;
 }
 
 }  // namespace ftr

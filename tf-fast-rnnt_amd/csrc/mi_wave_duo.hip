@@ -747,13 +747,6 @@ int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float*
 #undef FTR_DISPATCH
 }
 
-int debug_stamps(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) {
-    set_error("debug_stamps: hipMemcpyFromSymbol failed"); return FTR_ERR_LAUNCH;
-  }
-  return FTR_OK;
-}
-
 int selftest(hipStream_t st, int* result_dev) {
   // scratch lives behind result_dev: [0] result int, then 512 floats in, 512 floats out
   float* in = reinterpret_cast<float*>(result_dev + 4);

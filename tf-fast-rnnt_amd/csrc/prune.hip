@@ -171,33 +171,44 @@ __global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const
   const int lane = threadIdx.x;
   int count = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  // 4 candidates per lane and pass (16-byte loads where the row of `ranges` allows), list kept in index order
+  // 4 candidates per lane and pass (16-byte loads where the row of `ranges` allows), 8 passes' loads issued
+  // back to back before any of them is consumed (the scan is otherwise a chain of L2 round trips); the list
+  // is kept in index order
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(rg) & 15) == 0);
-  for (int base = 0; base < n; base += 256) {
-    const int i0 = base + 4 * lane;
-    int v[4];
-    if (vec_ok && i0 + 3 < n) {
-      const int4 q = *reinterpret_cast<const int4*>(rg + i0);
-      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
+  constexpr int UN = 8;
+  for (int base = 0; base < n; base += 256 * UN) {
+    int v[UN][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (i0 + e < n) ? rg[i0 + e] : -1;
+    for (int u = 0; u < UN; ++u) {
+      const int i0 = base + 256 * u + 4 * lane;
+      if (vec_ok && i0 + 3 < n) {
+        const int4 q = *reinterpret_cast<const int4*>(rg + i0);
+        v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = (i0 + e < n) ? rg[i0 + e] : -1;
+      }
     }
-    bool hit[4];
-    unsigned long long m[4];
-    int before = 0, total = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hit[e] = (v[e] == s);
-      m[e] = __ballot(hit[e]);
-      before += __popcll(m[e] & lt);
-      total += __popcll(m[e]);
+    for (int u = 0; u < UN; ++u) {
+      const int i0 = base + 256 * u + 4 * lane;
+      bool hit[4];
+      int before = 0, total = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hit[e] = (v[u][e] == s);
+        const unsigned long long m = __ballot(hit[e]);
+        before += __popcll(m & lt);
+        total += __popcll(m);
+      }
+      if (total != 0) {   // wave-uniform
+        int pos = count + before;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (hit[e]) lds_list[pos++] = i0 + e;
+        count += total;
+      }
     }
-    int pos = count + before;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (hit[e]) lds_list[pos++] = i0 + e;
-    count += total;
   }
   __syncthreads();   // one wave per block: orders the LDS list writes before the reads below
   const float* gb = g_lm_p + (size_t)b * n * C;
@@ -205,9 +216,18 @@ __global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const
   if (VEC) {
     const int n4 = C >> 2;
     for (int c = lane; c < n4; c += 64) {
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int j = 0; j < count; ++j) acc += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C)[c];
-      reinterpret_cast<f4u*>(out)[c] = acc;
+      // four independent partial sums (rows j = 0,1,2,3 mod 4) keep four loads in flight; they are combined in a
+      // fixed order, so the result is still deterministic
+      f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      int j = 0;
+      for (; j + 3 < count; j += 4) {
+        a0 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C)[c];
+        a1 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + 1] * C)[c];
+        a2 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + 2] * C)[c];
+        a3 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + 3] * C)[c];
+      }
+      for (; j < count; ++j) a0 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C)[c];
+      reinterpret_cast<f4u*>(out)[c] = (a0 + a1) + (a2 + a3);
     }
   } else {
     for (int c = lane; c < C; c += 64) {

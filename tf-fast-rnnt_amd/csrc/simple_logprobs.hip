@@ -37,7 +37,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // probs[row, :] = exp(x[row, :] - max(x[row, :])), rowmax[row] = max.  One wave per row.
 template <bool VEC>
 __global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict__ probs,
-                                  float* __restrict__ rowmax, size_t rows, int C) {
+                                  float* __restrict__ rowmax, float* __restrict__ rowsum, size_t rows, int C) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -50,17 +50,21 @@ __global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict
     const int n4 = C >> 2;
     for (int i = lane; i < n4; i += 64) { const f4 v = x4[i]; m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); }
     m = wave_max(m);
+    float sum = 0.0f;
     for (int i = lane; i < n4; i += 64) {
       const f4 v = x4[i];
       f4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = expf(v[e] - m);
+      for (int e = 0; e < 4; ++e) { o[e] = expf(v[e] - m); sum += o[e]; }
       p4[i] = o;
     }
+    if (rowsum) { sum = wave_sum(sum); if (lane == 0) rowsum[row] = sum; }
   } else {
     for (int i = lane; i < C; i += 64) m = fmaxf(m, xr[i]);
     m = wave_max(m);
-    for (int i = lane; i < C; i += 64) pr[i] = expf(xr[i] - m);
+    float sum = 0.0f;
+    for (int i = lane; i < C; i += 64) { const float o = expf(xr[i] - m); pr[i] = o; sum += o; }
+    if (rowsum) { sum = wave_sum(sum); if (lane == 0) rowsum[row] = sum; }
   }
   if (lane == 0) rowmax[row] = m;
 }
@@ -71,7 +75,11 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
                                   const int32_t* __restrict__ symbols, const float* __restrict__ prod,
                                   const float* __restrict__ am_max, const float* __restrict__ lm_max,
                                   const int32_t* __restrict__ boundary, int blank, double delay_penalty,
+                                  const float* __restrict__ lmonly_norm, const float* __restrict__ amonly_norm,
+                                  const float* __restrict__ ulog, float cs, float ls, float as,
                                   float* __restrict__ px, float* __restrict__ py, int T, int S, int C) {
+  // With lmonly_norm != NULL this is get_rnnt_logprobs_smoothed (rnnt_loss.py:1296-1365):
+  //   out = cs * (am + lm - normalizers) + ls * (lm - lmonly_norm[b,s]) + as * (am + ulog[c] - amonly_norm[b,t])
   extern __shared__ float tile[];  // [TT][C + 1]
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * TT;
@@ -109,17 +117,26 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   float pen = 0.0f;
   if (delay_penalty > 0.0) pen = (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty);  // :305-321
   const float* lmb = lm + (size_t)b * (S + 1) * C;
+  const bool smooth = lmonly_norm != nullptr;
+  const float aon = (smooth && t < T) ? amonly_norm[(size_t)b * T + t] : 0.0f;
+  const float ulog_blank = smooth ? ulog[blank] : 0.0f;
   for (int s = ty; s <= S; s += 8) {
     float nrm = 0.0f;
+    const float lon = smooth ? lmonly_norm[(size_t)b * (S + 1) + s] : 0.0f;
     if (t < T) {
       nrm = logf(prod[((size_t)b * (S + 1) + s) * T + t] + kTiny) + lm_max[(size_t)b * (S + 1) + s] + amx;  // :180-186
-      py[((size_t)b * (S + 1) + s) * T + t] = am_blank + lmb[(size_t)s * C + blank] - nrm;                  // :214-216
+      const float lmv = lmb[(size_t)s * C + blank];
+      float v = am_blank + lmv - nrm;                                                                       // :214-216
+      if (smooth) v = v * cs + (lmv - lon) * ls + (am_blank + ulog_blank - aon) * as;                       // :1333-1360
+      py[((size_t)b * (S + 1) + s) * T + t] = v;
     }
     if (s < S && t < T1) {
       float v = -INFINITY;  // px[:, :, T] (:193-203) and fix_for_boundary (:218-219)
       if (t < T && (MOD || t != te)) {
         const int sym = symbols[(size_t)b * S + s];
-        v = tile[tx * ld + sym] + lmb[(size_t)s * C + sym] - nrm;                                          // :187-211
+        const float amv = tile[tx * ld + sym], lmv = lmb[(size_t)s * C + sym];
+        v = amv + lmv - nrm;                                                                               // :187-211
+        if (smooth) v = v * cs + (lmv - lon) * ls + (amv + ulog[sym] - aon) * as;                           // :1323-1355
       }
       if (delay_penalty > 0.0) v += pen;
       px[((size_t)b * S + s) * T1 + t] = v;
@@ -133,7 +150,7 @@ template <bool MOD>
 __global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
                                     const float* __restrict__ prod, const int32_t* __restrict__ boundary,
                                     float* __restrict__ W, float* __restrict__ rsx, float* __restrict__ rsy,
-                                    int T, int S) {
+                                    float cs, int T, int S) {
   __shared__ float red[2][4];
   const int s = blockIdx.x, b = blockIdx.y;
   const int T1 = MOD ? T : T + 1;
@@ -146,7 +163,7 @@ __global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* 
     if (s < S && (MOD || t != te)) gx = gpx[rowx + t];
     const float gy = gpy[rowy + t];
     sx += gx; sy += gy;
-    W[rowy + t] = -(gx + gy) / (prod[rowy + t] + kTiny);
+    W[rowy + t] = -cs * (gx + gy) / (prod[rowy + t] + kTiny);   // cs = 1 for the simple loss
   }
   sx = wave_sum(sx); sy = wave_sum(sy);
   const int wv = threadIdx.x >> 6;
@@ -166,13 +183,19 @@ template <bool MOD>
 __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
                                      const float* __restrict__ damp, const float* __restrict__ am_probs,
                                      const int32_t* __restrict__ symbols, const int32_t* __restrict__ boundary,
-                                     int blank, float* __restrict__ d_am, int T, int S, int C) {
-  extern __shared__ float acc[];  // [TT][C + 1], then csy [8][TT]
+                                     int blank, float kdir, const float* __restrict__ uvec,
+                                     const float* __restrict__ amdot, float as, float* __restrict__ Rout,
+                                     float* __restrict__ d_am, int T, int S, int C) {
+  // Smoothed extension (uvec != NULL): the direct terms carry kdir = cs + as, and the AM-only normaliser
+  // log(am_probs . u) + am_max contributes  am_probs[b,t,c] * u[c] * R[b,t],  R = -as (colsum gpx' + colsum gpy) / dot;
+  // R is also written out (it feeds d u on the host side).
+  extern __shared__ float acc[];  // [TT][C + 1], then csy [8][TT], csx [8][TT]
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * TT;
   const int T1 = MOD ? T : T + 1;
   const int ld = C + 1;
   float* csy = acc + TT * ld;
+  float* csx = csy + 8 * TT;
   for (int i = threadIdx.x; i < TT * ld; i += blockDim.x) acc[i] = 0.0f;
   __syncthreads();
   const int tx = threadIdx.x & (TT - 1);
@@ -182,25 +205,36 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   const bool tok = t < T;
   const bool xok = tok && (MOD || t != te);
   const int32_t* symb = symbols + (size_t)b * S;
-  float cs = 0.0f;
+  float cs = 0.0f, cx = 0.0f;
   for (int s = 0; s < S; ++s) {
     const int sym = symb[s];
-    if ((sym & 7) == ty && xok) acc[tx * ld + sym] += gpx[((size_t)b * S + s) * T1 + t];
+    if ((sym & 7) == ty && xok) {
+      const float g = gpx[((size_t)b * S + s) * T1 + t];
+      acc[tx * ld + sym] += g;
+      cx += g;
+    }
   }
   for (int s = ty; s <= S; s += 8)
     if (tok) cs += gpy[((size_t)b * (S + 1) + s) * T + t];
   csy[ty * TT + tx] = cs;
+  csx[ty * TT + tx] = cx;
   __syncthreads();
   // write-out: two frames per pass, 16 bytes per lane along c where C allows
   {
     const int half = threadIdx.x >> 7, cl = threadIdx.x & 127;
     for (int tt = half; tt < TT; tt += 2) {
       if (t0 + tt >= T) continue;
-      float col = 0.0f;
+      float col = 0.0f, colx = 0.0f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) col += csy[g * TT + tt];
+      for (int g = 0; g < 8; ++g) { col += csy[g * TT + tt]; colx += csx[g * TT + tt]; }
       const size_t o = ((size_t)b * T + t0 + tt) * C;
       const float* arow = acc + tt * ld;
+      float R = 0.0f;
+      if (uvec) {
+        R = -as * (colx + col) / amdot[(size_t)b * T + t0 + tt];
+        if (cl == 0) Rout[(size_t)b * T + t0 + tt] = R;
+      }
+      col *= kdir;
       if ((C & 3) == 0) {
         const int n4 = C >> 2;
         for (int c4 = cl; c4 < n4; c4 += 128) {
@@ -209,15 +243,17 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
           f4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = dp[e] * ap[e] + arow[4 * c4 + e];
+            v[e] = dp[e] * ap[e] + kdir * arow[4 * c4 + e];
             if (4 * c4 + e == blank) v[e] += col;
+            if (uvec) v[e] += ap[e] * uvec[4 * c4 + e] * R;
           }
           reinterpret_cast<f4u*>(d_am + o)[c4] = v;
         }
       } else {
         for (int c = cl; c < C; c += 128) {
-          float v = damp[o + c] * am_probs[o + c] + arow[c];
+          float v = damp[o + c] * am_probs[o + c] + kdir * arow[c];
           if (c == blank) v += col;
+          if (uvec) v += am_probs[o + c] * uvec[c] * R;
           d_am[o + c] = v;
         }
       }
@@ -228,28 +264,33 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
 // one thread per element of d lm [B, S+1, C]
 __global__ void simple_bwd_lm_kernel(const float* __restrict__ dlmp, const float* __restrict__ lm_probs,
                                      const int32_t* __restrict__ symbols, const float* __restrict__ rsx,
-                                     const float* __restrict__ rsy, int blank, float* __restrict__ d_lm, int S,
-                                     int C, size_t total) {
+                                     const float* __restrict__ rsy, int blank, float kdir,
+                                     const float* __restrict__ arow, const float* __restrict__ invsum,
+                                     const float* __restrict__ gu, float* __restrict__ d_lm, int S, int C,
+                                     size_t total) {
+  // Smoothed extension (arow != NULL): direct terms carry kdir = cs + ls; the LM-only normaliser and the batch
+  // unigram contribute  lm_probs[b,s,c] * (arow[b,s] + gu[c] * invsum[b,s])  (host side prepares the vectors).
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t row = i / C;  // b*(S+1) + s
     const int c = (int)(i - row * C);
     const int s = (int)(row % (size_t)(S + 1));
     const size_t b = row / (size_t)(S + 1);
     float v = dlmp[i] * lm_probs[i];
-    if (s < S && c == symbols[b * S + s]) v += rsx[row];
-    if (c == blank) v += rsy[row];
+    if (s < S && c == symbols[b * S + s]) v += kdir * rsx[row];
+    if (c == blank) v += kdir * rsy[row];
+    if (arow) v += lm_probs[i] * (arow[row] + gu[c] * invsum[row]);
     d_lm[i] = v;
   }
 }
 
 }  // namespace
 
-int simple_rowmax_exp(const float* x, float* probs, float* rowmax, size_t rows, int C, hipStream_t st) {
+int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, size_t rows, int C, hipStream_t st) {
   if (rows == 0 || C == 0) return FTR_OK;
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
-  if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rows, C);
-  else hipLaunchKernelGGL(rowmax_exp_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rows, C);
+  if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, rows, C);
+  else hipLaunchKernelGGL(rowmax_exp_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, rows, C);
   return check_launch("rowmax_exp");
 }
 
@@ -269,7 +310,8 @@ static int reserve_lds(K kernel, size_t lds, const char* what) {
 
 int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols, const float* prod,
                         const float* am_max, const float* lm_max, const int32_t* boundary, int blank,
-                        double delay_penalty, float* px, float* py, int B, int T, int S, int C, int modified,
+                        double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog,
+                        float cs, float ls, float as, float* px, float* py, int B, int T, int S, int C, int modified,
                         hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)TT * (C + 1);
   int rc = tile_lds_ok(lds, "simple_logprobs_fwd");
@@ -278,46 +320,48 @@ int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols
   const dim3 grid((T1 + TT - 1) / TT, B);
   if (modified) {
     if ((rc = reserve_lds(simple_fwd_kernel<true>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_fwd_kernel<true>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, px, py, T, S, C);
+    hipLaunchKernelGGL(simple_fwd_kernel<true>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm, amonly_norm, ulog, cs, ls, as, px, py, T, S, C);
   } else {
     if ((rc = reserve_lds(simple_fwd_kernel<false>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_fwd_kernel<false>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, px, py, T, S, C);
+    hipLaunchKernelGGL(simple_fwd_kernel<false>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm, amonly_norm, ulog, cs, ls, as, px, py, T, S, C);
   }
   return check_launch("simple_logprobs_fwd");
 }
 
 int simple_logprobs_bwd_w(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
-                          float* W, float* rsx, float* rsy, int B, int T, int S, int modified, hipStream_t st) {
+                          float* W, float* rsx, float* rsy, float cs, int B, int T, int S, int modified, hipStream_t st) {
   const dim3 grid(S + 1, B);
-  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, T, S);
-  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, T, S);
+  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, cs, T, S);
+  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, cs, T, S);
   return check_launch("simple_logprobs_bwd_w");
 }
 
 int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
-                           const int32_t* symbols, const int32_t* boundary, int blank, float* d_am, int B, int T,
-                           int S, int C, int modified, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 8 * TT);
+                           const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec,
+                           const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C,
+                           int modified, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 16 * TT);
   int rc = tile_lds_ok(lds, "simple_logprobs_bwd_am");
   if (rc != FTR_OK) return rc;
   const dim3 grid((T + TT - 1) / TT, B);
   if (modified) {
     if ((rc = reserve_lds(simple_bwd_am_kernel<true>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_bwd_am_kernel<true>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, d_am, T, S, C);
+    hipLaunchKernelGGL(simple_bwd_am_kernel<true>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
   } else {
     if ((rc = reserve_lds(simple_bwd_am_kernel<false>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_bwd_am_kernel<false>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, d_am, T, S, C);
+    hipLaunchKernelGGL(simple_bwd_am_kernel<false>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
   }
   return check_launch("simple_logprobs_bwd_am");
 }
 
 int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx,
-                           const float* rsy, int blank, float* d_lm, int B, int S, int C, hipStream_t st) {
+                           const float* rsy, int blank, float kdir, const float* arow, const float* invsum,
+                           const float* gu, float* d_lm, int B, int S, int C, hipStream_t st) {
   const size_t total = (size_t)B * (S + 1) * C;
   if (total == 0) return FTR_OK;
   const size_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(simple_bwd_lm_kernel, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0, st,
-                     dlmp, lm_probs, symbols, rsx, rsy, blank, d_lm, S, C, total);
+                     dlmp, lm_probs, symbols, rsx, rsy, blank, kdir, arow, invsum, gu, d_lm, S, C, total);
   return check_launch("simple_logprobs_bwd_lm");
 }
 

@@ -19,6 +19,7 @@ _c_fp = ctypes.c_void_p   # const float* (device)
 _c_ip = ctypes.c_void_p   # const int32_t* (device)
 _c_st = ctypes.c_void_p   # hipStream_t
 _i = ctypes.c_int
+_f = ctypes.c_float
 
 _SIGNATURES = {
     "ftr_abi_version": (ctypes.c_int, []),
@@ -36,6 +37,11 @@ _SIGNATURES = {
     "ftr_pruned_logprobs_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_logprobs_bwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_rowmax_exp_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
+    "ftr_rowmax_exp_sum_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
+    "ftr_smoothed_logprobs_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, _f, _f, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_smoothed_logprobs_bwd_w_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_ip, _f, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
+    "ftr_smoothed_logprobs_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _f, _c_fp, _c_fp, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_smoothed_logprobs_bwd_lm_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_bwd_w_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),

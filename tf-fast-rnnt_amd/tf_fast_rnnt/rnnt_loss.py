@@ -8,7 +8,10 @@ What runs where:
   C ABI (include/ftr.h);
 * ``get_rnnt_logprobs`` / ``rnnt_loss_simple``: hand-written HIP prologue, epilogue and backward kernels around
   the normaliser GEMM (rocBLAS through torch.bmm);
-* the smoothed and joint (unpruned) px,py builders: torch ops for now -- SURVEY.md 8(f), "next".
+* ``get_rnnt_logprobs_smoothed`` / ``rnnt_loss_smoothed``: the same native kernels with the LM-only / AM-only
+  terms folded in; only the [C]- and [rows]-sized batch statistics (unigram mean, two matvecs) are torch ops;
+* ``get_rnnt_logprobs_joint`` / ``rnnt_loss`` (unpruned, joiner logits [B,T,S+1,C]): the pruned builder's kernels
+  with identity ranges (s_range = S+1).
 
 Reference bugs that are NOT reproduced: ``rnnt_loss_simple(reduction="mean")``
 raises NameError there (rnnt_loss.py:331) -- here it is the mean; ``boundary=None`` works; the
@@ -237,6 +240,11 @@ def rnnt_loss_simple(
     return _drive(px, py, boundary, reduction, calc_gradients)
 
 
+def _identity_ranges(B: int, T: int, S1: int, device) -> torch.Tensor:
+    """ranges[b,t,:] = 0..S: with every row in range the pruned builder IS the joint builder (its band is the lattice)."""
+    return torch.arange(S1, dtype=torch.int32, device=device).expand(B, T, S1).contiguous()
+
+
 def get_rnnt_logprobs_joint(
     logits: torch.Tensor,
     symbols: torch.Tensor,
@@ -244,7 +252,28 @@ def get_rnnt_logprobs_joint(
     boundary: Optional[torch.Tensor] = None,
     rnnt_type: str = "regular",
 ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """rnnt_loss.py:340-452.  logits [B,T,S+1,C] -> px, py."""
+    """rnnt_loss.py:340-452.  logits [B,T,S+1,C] -> px [B,S,T+1|T], py [B,S+1,T].  Native: the streaming
+    log-sum-exp + lattice writer of the pruned builder with s_range = S+1 (identity ranges), and the same
+    hand-written backward (d/d logits = scattered gradient - softmax * row sum)."""
+    _check_type(rnnt_type)
+    if logits.dim() != 4:
+        raise ValueError("logits must be [B,T,S+1,C]")
+    B, T, S1, C = logits.shape
+    if tuple(torch.as_tensor(symbols).shape) != (B, S1 - 1):
+        raise ValueError(f"symbols must have shape {(B, S1 - 1)}, got {tuple(torch.as_tensor(symbols).shape)}")
+    _require_gpu(logits, "logits")
+    return get_rnnt_logprobs_pruned(logits=logits, symbols=symbols, ranges=_identity_ranges(B, T, S1, logits.device),
+                                    termination_symbol=termination_symbol, boundary=boundary, rnnt_type=rnnt_type)
+
+
+def _get_rnnt_logprobs_joint_torch(
+    logits: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:340-452 op by op in torch.  Not on the product path: independent restatement for the tests."""
     _check_type(rnnt_type)
     B, T, S1, C = logits.shape
     S = S1 - 1
@@ -275,8 +304,16 @@ def rnnt_loss(
     reduction: Optional[str] = "mean",
     calc_gradients: bool = False,
 ) -> torch.Tensor:
-    """rnnt_loss.py:454-551 (unpruned loss on joiner logits [B,T,S+1,C])."""
+    """rnnt_loss.py:454-551 (unpruned loss on joiner logits [B,T,S+1,C]).  Without ``calc_gradients`` this is the
+    fused pruned loss with identity ranges (px/py, recursion forward+backward and d/d logits in native code)."""
+    _check_type(rnnt_type)
     boundary = _as_boundary(boundary, logits.shape[0], logits.device)
+    if not calc_gradients:
+        _require_gpu(logits, "logits")
+        B, T, S1, _ = logits.shape
+        return rnnt_loss_pruned(logits=logits, symbols=symbols, ranges=_identity_ranges(B, T, S1, logits.device),
+                                termination_symbol=termination_symbol, boundary=boundary, rnnt_type=rnnt_type,
+                                delay_penalty=delay_penalty, reduction=reduction)
     px, py = get_rnnt_logprobs_joint(logits=logits, symbols=symbols, termination_symbol=termination_symbol,
                                      boundary=boundary, rnnt_type=rnnt_type)
     px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
@@ -535,6 +572,109 @@ def rnnt_loss_pruned(
     return _reduce(negated_loss, reduction)
 
 
+class _SmoothedLogprobs(torch.autograd.Function):
+    """get_rnnt_logprobs_smoothed (+ fix_for_boundary) for regular/modified on the native builder kernels.
+
+    Forward (rnnt_loss.py:1265-1365): out = cs (x - normalizers) + ls (lm - lmonly_norm) + as (am + ulog - amonly_norm)
+    with lmonly_norm = log(rowsum lm_probs) + lm_max, u = mean_{b,s}(lm_probs / rowsum) + tiny, ulog = log u,
+    amonly_norm = log(am_probs . u) + am_max.  The lattice-sized work is in ftr_smoothed_logprobs_*; the batch
+    statistics ([C], [B,S+1] and [B,T] vectors, two matvecs) are torch ops on the same stream.
+
+    Backward, with gx = gpx masked where the forward wrote -inf, gy = gpy, rsx/rsy their sums over t and
+    colsum over s:
+      normalizers : W = -cs (gx+gy)/(prod+tiny), two GEMMs (as in _SimpleLogprobs)
+      direct      : am column sym/blank gets (cs+as) g, lm column sym/blank gets (cs+ls) g
+      lmonly_norm : d lm += -ls (rsx+rsy) * lm_probs / rowsum
+      amonly_norm : R[b,t] = -as colsum(gx+gy) / (am_probs . u);  d am += R am_probs u;  d u += R^T am_probs
+      ulog        : d u += as (sum of rsx by symbol + sum rsy at blank) / u
+      u           : gu = d u / N;  d lm += lm_probs/rowsum * (gu - (lm_probs/rowsum) . gu)
+    """
+
+    @staticmethod
+    def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale, am_only_scale,
+                process_group):
+        B, T, C = am.shape
+        S = lm.shape[1] - 1
+        T1 = T if modified else T + 1
+        cs = 1.0 - lm_only_scale - am_only_scale                    # :1342
+        ls = lm_only_scale if lm_only_scale != 0.0 else 1.0e-20       # :1346-1349
+        a_s = am_only_scale if am_only_scale != 0.0 else 1.0e-20
+        amc = am.detach().contiguous(); lmc = lm.detach().contiguous()
+        dev = amc.device
+        am_probs = torch.empty_like(amc); lm_probs = torch.empty_like(lmc)
+        am_max = torch.empty((B, T), dtype=torch.float32, device=dev)
+        lm_max = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        lm_sum = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        px = torch.empty((B, S, T1), dtype=torch.float32, device=dev)
+        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(amc)
+            _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)           # :1265-1268
+            _lib.call("ftr_rowmax_exp_sum_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), _ptr(lm_sum),
+                      B * (S + 1), C, st)                                                                   # :1276-1278
+            prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                            # :1270-1272
+            inv = 1.0 / lm_sum                                                                              # [B,S+1]
+            ratio_sum = torch.mv(lm_probs.reshape(-1, C).t(), inv.reshape(-1))                               # [C]
+            count = float(B * (S + 1))
+            if process_group is not None:
+                torch.distributed.all_reduce(ratio_sum, group=process_group)
+                count *= torch.distributed.get_world_size(process_group)
+            u = ratio_sum / count + _TINY                                                                   # :1279-1280
+            am_dot = torch.mv(am_probs.reshape(-1, C), u)                                                   # [B*T]
+            amonly = (am_dot.log().reshape(B, T) + am_max).contiguous()                                     # :1281-1286
+            ulog = u.log().contiguous()                                                                     # :1287
+            lmonly = (lm_sum.log() + lm_max).contiguous()                                                   # :1288-1290
+            _lib.call("ftr_smoothed_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
+                      _ptr(lm_max), _ptr(lmonly), _ptr(amonly), _ptr(ulog), _ptr(boundary), int(termination_symbol),
+                      cs, ls, a_s, _ptr(px), _ptr(py), B, T, S, C, int(modified), st)
+        ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0),
+                              inv, u, am_dot)
+        ctx.has_boundary = boundary is not None
+        ctx.meta = (int(termination_symbol), int(modified), cs, ls, a_s, count, process_group)
+        return px, py
+
+    @staticmethod
+    def backward(ctx, gpx, gpy):
+        am_probs, lm_probs, prod, symbols, boundary, inv, u, am_dot = ctx.saved_tensors
+        if not ctx.has_boundary:
+            boundary = None
+        blank, modified, cs, ls, a_s, count, group = ctx.meta
+        B, T, C = am_probs.shape
+        S = lm_probs.shape[1] - 1
+        dev = am_probs.device
+        gpx = gpx.contiguous(); gpy = gpy.contiguous()
+        W = torch.empty_like(prod)
+        rsx = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        rsy = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        R = torch.empty((B, T), dtype=torch.float32, device=dev)
+        d_am = torch.empty_like(am_probs); d_lm = torch.empty_like(lm_probs)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(am_probs)
+            _lib.call("ftr_smoothed_logprobs_bwd_w_f32", _ptr(gpx), _ptr(gpy), _ptr(prod), _ptr(boundary), cs, _ptr(W),
+                      _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
+            dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+            damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
+            _lib.call("ftr_smoothed_logprobs_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(damp), _ptr(am_probs),
+                      _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R), _ptr(d_am),
+                      B, T, S, C, modified, st)
+            # d u: through amonly_norm and through ulog
+            du = torch.mv(am_probs.reshape(-1, C).t(), R.reshape(-1))
+            gul = torch.zeros((C,), dtype=torch.float32, device=dev)
+            if S > 0:
+                gul.index_add_(0, _i64(symbols).reshape(-1), rsx[:, :S].reshape(-1))
+            gul[blank] += rsy.sum()
+            du = du + a_s * gul / u
+            if group is not None:
+                torch.distributed.all_reduce(du, group=group)
+            gu = (du / count).contiguous()
+            dotq = torch.mv(lm_probs.reshape(-1, C), gu).reshape(B, S + 1) * inv
+            arow = ((-ls) * (rsx + rsy) - dotq) * inv
+            arow = arow.contiguous()
+            _lib.call("ftr_smoothed_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx),
+                      _ptr(rsy), blank, cs + ls, _ptr(arow), _ptr(inv), _ptr(gu), _ptr(d_lm), B, S, C, st)
+        return d_lm, d_am, None, None, None, None, None, None, None
+
+
 def get_rnnt_logprobs_smoothed(
     lm: torch.Tensor,
     am: torch.Tensor,
@@ -546,9 +686,45 @@ def get_rnnt_logprobs_smoothed(
     rnnt_type: str = "regular",
     process_group=None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """rnnt_loss.py:1132-1367.  ``process_group`` (extension, default None = local batch only): when the
-    batch is sharded over ranks, the batch-wide ``unigram_lm`` mean (rnnt_loss.py:1279-1280) is
-    all-reduced (one [C] vector over RCCL, differentiable) so every shard sees the global-batch value."""
+    """rnnt_loss.py:1132-1367, native (HIP) builder, differentiable w.r.t. lm and am.  ``process_group``
+    (extension, default None = local batch only): when the batch is sharded over ranks, the batch-wide
+    ``unigram_lm`` mean (rnnt_loss.py:1279-1280) is all-reduced (one [C] vector over RCCL forward, one backward)
+    so every shard sees the global-batch value."""
+    _check_type(rnnt_type)
+    _require_gpu(am, "am"); _require_gpu(lm, "lm")
+    if am.dtype != torch.float32 or lm.dtype != torch.float32:
+        raise TypeError("am and lm must be float32")
+    B, T, C = am.shape
+    S = lm.shape[1] - 1
+    if lm.shape[0] != B or lm.shape[2] != C:
+        raise ValueError(f"lm {tuple(lm.shape)} and am {tuple(am.shape)} disagree")
+    symbols = torch.as_tensor(symbols, device=am.device)
+    if tuple(symbols.shape) != (B, S):
+        raise ValueError(f"symbols must have shape {(B, S)}, got {tuple(symbols.shape)}")
+    if not 0 <= int(termination_symbol) < C:
+        raise ValueError(f"termination_symbol {termination_symbol} not in [0, {C})")
+    symbols = symbols.to(torch.int32).contiguous()
+    boundary = _as_boundary(boundary, B, am.device)
+    px, py = _SmoothedLogprobs.apply(lm, am, symbols, termination_symbol, boundary, rnnt_type != "regular",
+                                     float(lm_only_scale), float(am_only_scale), process_group)
+    if rnnt_type == "constrained":
+        px = px + py[:, 1:, :]                                                                              # :1362-1363
+    return px, py
+
+
+def _get_rnnt_logprobs_smoothed_torch(
+    lm: torch.Tensor,
+    am: torch.Tensor,
+    symbols: torch.Tensor,
+    termination_symbol: int,
+    lm_only_scale: float = 0.1,
+    am_only_scale: float = 0.1,
+    boundary: Optional[torch.Tensor] = None,
+    rnnt_type: str = "regular",
+    process_group=None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:1132-1367 op by op in torch (the shape the reference has it in).  Not on the product path:
+    an independent restatement for the tests (autograd in float64 checks the hand-written backward)."""
     _check_type(rnnt_type)
     B, T, C = am.shape
     S = lm.shape[1] - 1
