@@ -131,6 +131,7 @@ CALL_KERNELS = {
     "ftr_prune_ranges_i32": ["prune_argmax_kernel", "prune_adjust_kernel"],
     "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
+    "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_chunk_kernel<true>", "do_pruning_bwd_reduce_kernel"],
     "ftr_pruned_logprobs_fwd_f32": ["lse_rows_kernel<true>", "band_to_lattice_kernel<false>"],
     "ftr_pruned_logprobs_bwd_f32": ["band_grad_kernel<false, true>"],
     "ftr_rowmax_exp_f32": ["rowmax_exp_kernel<true>"],
@@ -178,6 +179,7 @@ def algorithmic_bytes(B, T, S, C, r):
         "ftr_simple_logprobs_bwd_lm_f32": 4 * 3 * nlm,
         "ftr_smoothed_logprobs_bwd_lm_f32": 4 * 3 * nlm,
         "ftr_do_pruning_bwd_f32": 2 * N + 4 * (nam + nlm + B * T * r),      # read both pruned gradients, write d am, d lm
+        "ftr_do_pruning_bwd_ws_f32": N + 4 * (nam + nlm + B * T * r),       # the joiner's gradient is ONE tensor: read once
         # fwd reads px,py and writes p; bwd (reference algorithm) reads px,py,p and writes both grads: 32 L total
         "ftr_mutual_information_fwd_f32": 4 * (npx + npy + L),
         "ftr_mutual_information_bwd_f32": 4 * (npx + npy + L + npx + npy),

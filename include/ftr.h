@@ -113,6 +113,18 @@ int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, 
 int ftr_do_pruning_bwd_f32(const float* g_am_pruned, const float* g_lm_pruned, const int32_t* ranges, float* d_am,
                            float* d_lm, int B, int T, int S1, int C, int r, void* stream);
 
+/* The same backward with a caller-provided scratch buffer (ftr_do_pruning_bwd_workspace_bytes() bytes, 16-byte
+ * aligned, contents irrelevant): the incoming gradient is streamed once in chunks of 16 frames, each chunk's rows are
+ * summed per lattice row in LDS in (t,k) order, and the per-chunk partial rows are then added in chunk order
+ * (deterministic, no atomics; the association differs from the plain left-to-right sum of the function above).
+ * When g_am_pruned == g_lm_pruned (a joiner that starts with am_pruned + lm_pruned hands the same buffer to both)
+ * d_am comes out of the same pass.  Arbitrary `ranges` are accepted.  Falls back to the kernels above when
+ * C % 4 != 0. */
+size_t ftr_do_pruning_bwd_workspace_bytes(int B, int T, int S1, int C, int r);
+int ftr_do_pruning_bwd_ws_f32(const float* g_am_pruned, const float* g_lm_pruned, const int32_t* ranges, float* d_am,
+                              float* d_lm, int B, int T, int S1, int C, int r, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /*
  * Pruned log-probs, forward.  Replaces get_rnnt_logprobs_pruned for rnnt_type "regular"
  * (modified==0) / "modified" (modified!=0) (rnnt_loss.py:853-1020: logsumexp, two gathers, pad,

@@ -330,3 +330,37 @@ def test_native_joint_builder_and_unpruned_loss(ft, dev, oracle, rnnt_type):
     tot.backward()
     assert abs(tot.item() - loss.item()) <= 1e-4 * abs(tot.item())
     assert max_rel(logits.grad.cpu().numpy(), l64.grad.cpu().numpy()) <= 1e-4
+
+
+@pytest.mark.parametrize("same_tensor", [True, False])
+@pytest.mark.parametrize("kind", ["monotone", "scattered", "wide"])
+def test_do_pruning_backward_chunked(ft, dev, kind, same_tensor):
+    """The chunked (workspace) backward of the prune gather on caller-chosen ranges: monotone bands (bins path),
+    rows scattered over the whole lattice and bands wider than the bin budget (both take the overflow path of
+    pass 2), with the two incoming gradients being one tensor (fused d_am) or two.  float64 segment sums as reference;
+    tolerance 1e-5 relative (f32 sums in a different association)."""
+    B, T, S1, C, r = 3, 70, 40, 24, 5
+    g = torch.Generator(device="cpu").manual_seed(17)
+    if kind == "monotone":
+        s0 = torch.sort(torch.randint(0, S1 - r + 1, (B, T), generator=g), dim=1).values
+        ranges = s0.unsqueeze(2) + torch.arange(r)
+    elif kind == "scattered":
+        ranges = torch.randint(0, S1, (B, T, r), generator=g)
+    else:   # consecutive frames jump by more than the bin budget
+        s0 = (torch.arange(T) * 7) % (S1 - r + 1)
+        ranges = (s0.unsqueeze(1) + torch.arange(r)).expand(B, T, r).clone()
+    ranges = ranges.to(torch.int32).to(dev)
+    am = torch.randn((B, T, C), generator=g).to(dev).requires_grad_(True)
+    lm = torch.randn((B, S1, C), generator=g).to(dev).requires_grad_(True)
+    am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
+    w = torch.randn((B, T, r, C), generator=g).to(dev)
+    if same_tensor:
+        ((am_p + lm_p) * w).sum().backward()          # autograd hands one buffer to both inputs
+        w2 = w
+    else:
+        w2 = torch.randn((B, T, r, C), generator=g).to(dev)
+        ((am_p * w).sum() + (lm_p * w2).sum()).backward()
+    np.testing.assert_allclose(am.grad.cpu().numpy(), w.double().sum(dim=2).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    want = torch.zeros((B, S1, C), dtype=torch.float64, device=dev)
+    want.index_put_((torch.arange(B, device=dev).view(B, 1, 1).expand(B, T, r), ranges.long()), w2.double(), accumulate=True)
+    np.testing.assert_allclose(lm.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)

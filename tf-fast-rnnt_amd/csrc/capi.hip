@@ -150,6 +150,23 @@ int ftr_do_pruning_bwd_f32(const float* g_am_pruned, const float* g_lm_pruned, c
   return do_pruning_bwd(g_am_pruned, g_lm_pruned, ranges, d_am, d_lm, B, T, S1, C, r, reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t ftr_do_pruning_bwd_workspace_bytes(int B, int T, int S1, int C, int r) {
+  if (B < 0 || T < 0 || S1 < 1 || C < 0 || r < 0) return 0;
+  return do_pruning_bwd_workspace_bytes(B, T, S1, C, r);
+}
+
+int ftr_do_pruning_bwd_ws_f32(const float* g_am_pruned, const float* g_lm_pruned, const int32_t* ranges, float* d_am,
+                              float* d_lm, int B, int T, int S1, int C, int r, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 0 && S1 >= 1 && C >= 0 && r >= 0, "do_pruning_bwd_ws: bad sizes");
+  if ((size_t)B * C == 0) return FTR_OK;
+  FTR_REQUIRE(g_am_pruned && g_lm_pruned && ranges && d_am && d_lm, "do_pruning_bwd_ws: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return do_pruning_bwd_ws(g_am_pruned, g_lm_pruned, ranges, d_am, d_lm, B, T, S1, C, r, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ftr_pruned_logprobs_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
                                 const int32_t* boundary, int termination_symbol, double delay_penalty,
                                 float* lse, float* px, float* py, int B, int T, int S, int C, int r,

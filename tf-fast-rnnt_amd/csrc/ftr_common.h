@@ -58,6 +58,8 @@ size_t mi_chain_extra_floats(int B, int S, int T);
 int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st);
 int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boundary, int32_t* ranges, int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st);
 int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1, int C, int r, hipStream_t st);
+size_t do_pruning_bwd_workspace_bytes(int B, int T, int S1, int C, int r);
+int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B, int T, int S1, int C, int r, void* ws, size_t ws_bytes, hipStream_t st);
 int do_pruning_bwd(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B, int T, int S1, int C, int r, hipStream_t st);
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, const float* scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);

@@ -59,14 +59,31 @@ __global__ void prune_argmax_kernel(const float* __restrict__ px_grad, const flo
   for (int s = 0; s < r; ++s) lead = lead + pyc[(size_t)s * T];
   int best = 0;
   float bestv = 0.0f;
-  for (int s0 = 0; s0 < nwin; ++s0) {
-    const float blk = lead - lag;                                        // rnnt_loss.py:725
-    const float pxp = (s0 == 0) ? 0.0f : pxc[(size_t)(s0 - 1) * T1];     // :726-727
-    const float fin = blk - pxp;                                         // :728
-    if (s0 == 0 || fin > bestv) { best = s0; bestv = fin; }              // :729, first maximum
-    if (s0 + 1 < nwin) {
-      lead = lead + pyc[(size_t)(s0 + r) * T];
-      lag = lag + pyc[(size_t)s0 * T];
+  // The cumulative sums must be taken in this order (bit-exact ranges), but the loads do not depend on them: fetch
+  // CHK windows' worth of operands first (3 * CHK independent loads in flight), then run the serial arithmetic.
+  constexpr int CHK = 32;
+  for (int c0 = 0; c0 < nwin; c0 += CHK) {
+    float ld[CHK], lg[CHK], xv[CHK];
+#pragma unroll
+    for (int u = 0; u < CHK; ++u) {
+      const int s0 = c0 + u;
+      const bool more = s0 + 1 < nwin;
+      ld[u] = more ? pyc[(size_t)(s0 + r) * T] : 0.0f;
+      lg[u] = more ? pyc[(size_t)s0 * T] : 0.0f;
+      xv[u] = (s0 > 0 && s0 < nwin) ? pxc[(size_t)(s0 - 1) * T1] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < CHK; ++u) {
+      const int s0 = c0 + u;
+      if (s0 < nwin) {
+        const float blk = lead - lag;                                      // rnnt_loss.py:725
+        const float fin = blk - xv[u];                                     // :726-728 (px_pad[.,0] = 0)
+        if (s0 == 0 || fin > bestv) { best = s0; bestv = fin; }            // :729, first maximum
+        if (s0 + 1 < nwin) {
+          lead = lead + ld[u];
+          lag = lag + lg[u];
+        }
+      }
     }
   }
   const int se = boundary[4 * b + 2], te = boundary[4 * b + 3];
@@ -215,19 +232,38 @@ __global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const
   float* out = d_lm + ((size_t)b * S1 + s) * C;
   if (VEC) {
     const int n4 = C >> 2;
-    for (int c = lane; c < n4; c += 64) {
-      // four independent partial sums (rows j = 0,1,2,3 mod 4) keep four loads in flight; they are combined in a
-      // fixed order, so the result is still deterministic
-      f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    // two column quads per lane (c, c + 64) x eight rows = 16 independent 16-byte loads in flight per lane; the
+    // eight partial sums are combined in a fixed order, so the result is deterministic
+    for (int c = lane; c < n4; c += 128) {
+      const int c2 = c + 64;
+      const bool two = c2 < n4;
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      f4 a[4] = {z, z, z, z}, d[4] = {z, z, z, z};
       int j = 0;
-      for (; j + 3 < count; j += 4) {
-        a0 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C)[c];
-        a1 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + 1] * C)[c];
-        a2 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + 2] * C)[c];
-        a3 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + 3] * C)[c];
+      for (; j + 7 < count; j += 8) {
+        f4 x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const f4u* row = reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j + u] * C);
+          x[u] = row[c];
+          y[u] = two ? row[c2] : z;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] += x[u]; d[u] += y[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] += x[u + 4]; d[u] += y[u + 4];
+        }
       }
-      for (; j < count; ++j) a0 += reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C)[c];
-      reinterpret_cast<f4u*>(out)[c] = (a0 + a1) + (a2 + a3);
+      for (; j < count; ++j) {
+        const f4u* row = reinterpret_cast<const f4u*>(gb + (size_t)lds_list[j] * C);
+        a[0] += row[c];
+        if (two) d[0] += row[c2];
+      }
+      reinterpret_cast<f4u*>(out)[c] = (a[0] + a[1]) + (a[2] + a[3]);
+      if (two) reinterpret_cast<f4u*>(out)[c2] = (d[0] + d[1]) + (d[2] + d[3]);
     }
   } else {
     for (int c = lane; c < C; c += 64) {
@@ -236,6 +272,118 @@ __global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const
       out[c] = acc;
     }
   }
+}
+
+
+// ---- chunked backward of the prune gather (16-byte path, C % 4 == 0): g is streamed exactly once.
+// Pass 1, one block per (utterance, TCH consecutive frames): the TCH*r rows of the chunk are contiguous in memory;
+// thread i owns the column quads i, i+128, ...  and walks the rows in (t,k) order, adding each row into the LDS bin
+// of its lattice row s = ranges[b,t,k] (bins cover [smin, smin+nb) of the chunk; a thread only ever touches its own
+// columns: no atomics, no barriers, fixed order).  When the two incoming gradients are the same tensor (the joiner
+// starts with am_pruned + lm_pruned, so autograd hands the same buffer to both) the sum over k that gives d am is
+// taken from the same registers (FUSE).  The bins go to `partial` [B][nchunks][nbmax][C]; meta = {smin, nb}.
+// A chunk whose rows span more than nbmax lattice rows (never for get_rnnt_prune_ranges output at sane sizes, but
+// `ranges` is caller data) is marked nb = -1 and left to pass 2.
+// Pass 2, one block per (b,s): adds the (at most a few) partial rows that cover s in chunk order; for chunks marked
+// -1 it scans the chunk's ranges and adds the matching rows of g directly.
+constexpr int TCH = 16;
+
+template <bool FUSE>
+__global__ __launch_bounds__(128) void do_pruning_bwd_chunk_kernel(
+    const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, float* __restrict__ d_am,
+    float* __restrict__ partial, int2* __restrict__ meta, int T, int C, int r, int nbmax) {
+  extern __shared__ __attribute__((aligned(16))) float bins[];   // [nbmax][C], then int rs[TCH * r]
+  __shared__ int red[4];
+  int* rs = reinterpret_cast<int*>(bins + (size_t)nbmax * C);
+  const int chunk = blockIdx.x, b = blockIdx.y, nchunks = gridDim.x;
+  const int t0 = chunk * TCH;
+  const int nf = min(TCH, T - t0);
+  const int nrows = nf * r;
+  const int32_t* rg = ranges + ((size_t)b * T + t0) * r;
+  int lo = INT_MAX, hi = INT_MIN;
+  for (int i = threadIdx.x; i < nrows; i += 128) {
+    const int v = rg[i];
+    rs[i] = v;
+    lo = min(lo, v); hi = max(hi, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = lo; red[(threadIdx.x >> 6) * 2 + 1] = hi; }
+  __syncthreads();
+  const int smin = min(red[0], red[2]), smax = max(red[1], red[3]);
+  const int nb = smax - smin + 1;
+  const bool ok = smin >= 0 && nb <= nbmax;
+  if (threadIdx.x == 0) meta[(size_t)b * nchunks + chunk] = ok ? make_int2(smin, nb) : make_int2(0, -1);
+  if (!ok && !FUSE) return;
+  const int n4 = C >> 2;
+  const size_t row0 = ((size_t)b * T + t0) * r;
+  for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
+    f4* mybin = reinterpret_cast<f4*>(bins) + c4;          // bin j at mybin[j * n4]
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+      for (int j = 0; j < nb; ++j) mybin[(size_t)j * n4] = z;
+    const f4u* g = reinterpret_cast<const f4u*>(g_lm_p + row0 * C) + c4;   // row i at g[i * n4]
+    f4 asum = z;
+    int k = 0, f = 0;
+    for (int i0 = 0; i0 < nrows; i0 += 8) {
+      f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i0 + u < nrows) ? (f4)g[(size_t)(i0 + u) * n4] : z;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u < nrows) {
+          if (ok) {
+            f4* dst = mybin + (size_t)(rs[i0 + u] - smin) * n4;
+            *dst = *dst + v[u];
+          }
+          if (FUSE) {
+            asum += v[u];
+            if (++k == r) {
+              reinterpret_cast<f4u*>(d_am + ((size_t)b * T + t0 + f) * C)[c4] = asum;
+              asum = z; k = 0; ++f;
+            }
+          }
+        }
+      }
+    }
+    if (ok) {
+      f4u* out = reinterpret_cast<f4u*>(partial + ((size_t)b * nchunks + chunk) * nbmax * C) + c4;
+      for (int j = 0; j < nb; ++j) out[(size_t)j * n4] = mybin[(size_t)j * n4];
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void do_pruning_bwd_reduce_kernel(
+    const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, const float* __restrict__ partial,
+    const int2* __restrict__ meta, float* __restrict__ d_lm, int T, int S1, int C, int r, int nbmax, int nchunks) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int n4 = C >> 2;
+  for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int2 m = meta[(size_t)b * nchunks + ch];   // wave-uniform
+      if (m.y > 0) {
+        const int bin = s - m.x;
+        if (bin >= 0 && bin < m.y)
+          acc += reinterpret_cast<const f4u*>(partial + (((size_t)b * nchunks + ch) * nbmax + bin) * C)[c4];
+      } else if (m.y < 0) {
+        const int t0 = ch * TCH;
+        const int nrows = min(TCH, T - t0) * r;
+        const size_t row0 = ((size_t)b * T + t0) * r;
+        for (int i = 0; i < nrows; ++i)
+          if (ranges[row0 + i] == s) acc += reinterpret_cast<const f4u*>(g_lm_p + (row0 + i) * C)[c4];
+      }
+    }
+    reinterpret_cast<f4u*>(d_lm + ((size_t)b * S1 + s) * C)[c4] = acc;
+  }
+}
+
+inline int chunk_nbmax(int C) {
+  const int n = (64 * 1024) / (4 * (C > 0 ? C : 1));
+  return n < 4 ? 4 : (n > 16 ? 16 : n);
 }
 
 }  // namespace
@@ -304,6 +452,49 @@ int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* a
                        am, lm, ranges, am_p, lm_p, T, S1, C, r, total);
   }
   return check_launch("do_pruning");
+}
+
+size_t do_pruning_bwd_workspace_bytes(int B, int T, int S1, int C, int r) {
+  if ((C & 3) != 0 || (size_t)B * T * C == 0) return 0;
+  const size_t nchunks = (size_t)(T + ftr::TCH - 1) / ftr::TCH;
+  const size_t partial = sizeof(float) * (size_t)B * nchunks * ftr::chunk_nbmax(C) * C;
+  return partial + sizeof(int2) * (size_t)B * nchunks;
+}
+
+int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm,
+                      int B, int T, int S1, int C, int r, void* ws, size_t ws_bytes, hipStream_t st) {
+  if ((size_t)B * T * C == 0) return FTR_OK;
+  if ((C & 3) != 0 || r <= 0) return do_pruning_bwd(g_am_p, g_lm_p, ranges, d_am, d_lm, B, T, S1, C, r, st);
+  const size_t need = do_pruning_bwd_workspace_bytes(B, T, S1, C, r);
+  if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 15) != 0) {
+    set_error("do_pruning_bwd_ws: workspace of %zu bytes (16-byte aligned) required, got %zu", need, ws_bytes);
+    return FTR_ERR_INVALID_ARG;
+  }
+  const int nbmax = ftr::chunk_nbmax(C);
+  const int nchunks = (T + ftr::TCH - 1) / ftr::TCH;
+  float* partial = reinterpret_cast<float*>(ws);
+  int2* meta = reinterpret_cast<int2*>(partial + (size_t)B * nchunks * nbmax * C);
+  const size_t lds = sizeof(float) * (size_t)nbmax * C + sizeof(int) * (size_t)ftr::TCH * r;
+  if (lds > 150 * 1024) return do_pruning_bwd(g_am_p, g_lm_p, ranges, d_am, d_lm, B, T, S1, C, r, st);
+  const bool fuse = (g_am_p == g_lm_p);
+  if (lds > 64 * 1024) {
+    hipError_t e = fuse ? hipFuncSetAttribute(reinterpret_cast<const void*>(ftr::do_pruning_bwd_chunk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                        : hipFuncSetAttribute(reinterpret_cast<const void*>(ftr::do_pruning_bwd_chunk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("do_pruning_bwd_ws: cannot reserve LDS: %s", hipGetErrorString(e)); return FTR_ERR_LAUNCH; }
+  }
+  if (!fuse) {
+    const size_t total = (size_t)B * T * (C >> 2);
+    hipLaunchKernelGGL(ftr::do_pruning_bwd_am_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g_am_p, d_am, C, r, total);
+    int rc = check_launch("do_pruning_bwd_am");
+    if (rc != FTR_OK) return rc;
+    hipLaunchKernelGGL(ftr::do_pruning_bwd_chunk_kernel<false>, dim3(nchunks, B), dim3(128), lds, st, g_lm_p, ranges, d_am, partial, meta, T, C, r, nbmax);
+  } else {
+    hipLaunchKernelGGL(ftr::do_pruning_bwd_chunk_kernel<true>, dim3(nchunks, B), dim3(128), lds, st, g_lm_p, ranges, d_am, partial, meta, T, C, r, nbmax);
+  }
+  int rc = check_launch("do_pruning_bwd_chunk");
+  if (rc != FTR_OK) return rc;
+  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(128), 0, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, nbmax, nchunks);
+  return check_launch("do_pruning_bwd_reduce");
 }
 
 }  // namespace ftr

@@ -22,7 +22,44 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// logsumexp of each row of length C; rows = B*T*r.  One wave per row.
+// logsumexp of each row, the row held in registers (C % 4 == 0, C <= 256 * NQ): one 16-byte load per lane and quad,
+// all of a wave's loads (RW rows x NQ quads) issued before the first is used, a single pass over the data.
+template <int NQ, int RW>
+__global__ void lse_rows_reg_kernel(const float* __restrict__ logits, float* __restrict__ lse, size_t rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t row0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RW;
+  if (row0 >= rows) return;
+  const int n4 = C >> 2;
+  f4 v[RW][NQ];
+#pragma unroll
+  for (int w = 0; w < RW; ++w) {
+    const size_t row = (row0 + w < rows) ? row0 + w : rows - 1;   // tail: recompute the last row, write guarded below
+    const f4u* x4 = reinterpret_cast<const f4u*>(logits + row * C);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = lane + 64 * q;
+      const f4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      v[w][q] = (i < n4) ? (f4)x4[i] : ninf;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < RW; ++w) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(v[w][q][0], v[w][q][1])), fmaxf(v[w][q][2], v[w][q][3]));
+    m = wave_max(m);
+    float sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel: bit-identical lse
+        sum += __expf(v[w][q][0] - m) + __expf(v[w][q][1] - m) + __expf(v[w][q][2] - m) + __expf(v[w][q][3] - m);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0 && row0 + w < rows) lse[row0 + w] = m + __logf(sum);
+  }
+}
+
+// logsumexp of each row of length C; rows = B*T*r.  One wave per row (any C).
 template <bool VEC>
 __global__ void lse_rows_kernel(const float* __restrict__ logits, float* __restrict__ lse, size_t rows, int C) {
   const int lane = threadIdx.x & 63;
@@ -154,7 +191,12 @@ int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32
   if (rows == 0) return FTR_OK;
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
-  if ((C & 3) == 0) hipLaunchKernelGGL(lse_rows_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  constexpr int RW = 2;
+  const unsigned blocks_reg = (unsigned)((rows + (size_t)wpb * RW - 1) / ((size_t)wpb * RW));
+  if ((C & 3) == 0 && C <= 256) hipLaunchKernelGGL((lse_rows_reg_kernel<1, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 512) hipLaunchKernelGGL((lse_rows_reg_kernel<2, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 1024) hipLaunchKernelGGL((lse_rows_reg_kernel<4, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0) hipLaunchKernelGGL(lse_rows_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else hipLaunchKernelGGL(lse_rows_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   int rc = check_launch("lse_rows");
   if (rc != FTR_OK) return rc;

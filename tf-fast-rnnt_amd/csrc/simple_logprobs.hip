@@ -107,6 +107,25 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
           tile[tt * ld + c] = (t0 + tt < T) ? amb[(size_t)(t0 + tt) * C + c] : 0.0f;
     }
   }
+  // per-row scalars (symbol, lm at the symbol, lm at blank, lm_max, lmonly_norm) staged once: in the sweep below only
+  // `prod` is a global load, so the compiler can keep several rows in flight
+  const float* lmb = lm + (size_t)b * (S + 1) * C;
+  const bool smooth = lmonly_norm != nullptr;
+  float* rs_lmsym = tile + TT * ld;          // [S+1] each
+  float* rs_lmblank = rs_lmsym + (S + 1);
+  float* rs_lmmax = rs_lmblank + (S + 1);
+  float* rs_lon = rs_lmmax + (S + 1);
+  float* rs_ulog = rs_lon + (S + 1);
+  int* rs_sym = reinterpret_cast<int*>(rs_ulog + (S + 1));
+  for (int s = threadIdx.x; s <= S; s += blockDim.x) {
+    const int sym = (s < S) ? symbols[(size_t)b * S + s] : blank;
+    rs_sym[s] = sym;
+    rs_lmsym[s] = lmb[(size_t)s * C + sym];
+    rs_lmblank[s] = lmb[(size_t)s * C + blank];
+    rs_lmmax[s] = lm_max[(size_t)b * (S + 1) + s];
+    rs_lon[s] = smooth ? lmonly_norm[(size_t)b * (S + 1) + s] : 0.0f;
+    rs_ulog[s] = smooth ? ulog[sym] : 0.0f;
+  }
   __syncthreads();
   const int tx = threadIdx.x & (TT - 1);
   const int ty = threadIdx.x >> 5;
@@ -116,16 +135,16 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   const float am_blank = tile[tx * ld + blank];
   float pen = 0.0f;
   if (delay_penalty > 0.0) pen = (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty);  // :305-321
-  const float* lmb = lm + (size_t)b * (S + 1) * C;
-  const bool smooth = lmonly_norm != nullptr;
   const float aon = (smooth && t < T) ? amonly_norm[(size_t)b * T + t] : 0.0f;
   const float ulog_blank = smooth ? ulog[blank] : 0.0f;
+  const float* prodb = prod + (size_t)b * (S + 1) * T + t;
+#pragma unroll 4
   for (int s = ty; s <= S; s += 8) {
     float nrm = 0.0f;
-    const float lon = smooth ? lmonly_norm[(size_t)b * (S + 1) + s] : 0.0f;
+    const float lon = rs_lon[s];
     if (t < T) {
-      nrm = logf(prod[((size_t)b * (S + 1) + s) * T + t] + kTiny) + lm_max[(size_t)b * (S + 1) + s] + amx;  // :180-186
-      const float lmv = lmb[(size_t)s * C + blank];
+      nrm = logf(prodb[(size_t)s * T] + kTiny) + rs_lmmax[s] + amx;                                          // :180-186
+      const float lmv = rs_lmblank[s];
       float v = am_blank + lmv - nrm;                                                                       // :214-216
       if (smooth) v = v * cs + (lmv - lon) * ls + (am_blank + ulog_blank - aon) * as;                       // :1333-1360
       py[((size_t)b * (S + 1) + s) * T + t] = v;
@@ -133,10 +152,9 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
     if (s < S && t < T1) {
       float v = -INFINITY;  // px[:, :, T] (:193-203) and fix_for_boundary (:218-219)
       if (t < T && (MOD || t != te)) {
-        const int sym = symbols[(size_t)b * S + s];
-        const float amv = tile[tx * ld + sym], lmv = lmb[(size_t)s * C + sym];
+        const float amv = tile[tx * ld + rs_sym[s]], lmv = rs_lmsym[s];
         v = amv + lmv - nrm;                                                                               // :187-211
-        if (smooth) v = v * cs + (lmv - lon) * ls + (amv + ulog[sym] - aon) * as;                           // :1323-1355
+        if (smooth) v = v * cs + (lmv - lon) * ls + (amv + rs_ulog[s] - aon) * as;                          // :1323-1355
       }
       if (delay_penalty > 0.0) v += pen;
       px[((size_t)b * S + s) * T1 + t] = v;
@@ -189,7 +207,7 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   // Smoothed extension (uvec != NULL): the direct terms carry kdir = cs + as, and the AM-only normaliser
   // log(am_probs . u) + am_max contributes  am_probs[b,t,c] * u[c] * R[b,t],  R = -as (colsum gpx' + colsum gpy) / dot;
   // R is also written out (it feeds d u on the host side).
-  extern __shared__ float acc[];  // [TT][C + 1], then csy [8][TT], csx [8][TT]
+  extern __shared__ float acc[];  // [TT][C + 1], then csy [8][TT], csx [8][TT], then u16 row lists [8][S]
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * TT;
   const int T1 = MOD ? T : T + 1;
@@ -205,17 +223,46 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   const bool tok = t < T;
   const bool xok = tok && (MOD || t != te);
   const int32_t* symb = symbols + (size_t)b * S;
-  float cs = 0.0f, cx = 0.0f;
-  for (int s = 0; s < S; ++s) {
-    const int sym = symb[s];
-    if ((sym & 7) == ty && xok) {
-      const float g = gpx[((size_t)b * S + s) * T1 + t];
-      acc[tx * ld + sym] += g;
-      cx += g;
+  // rows grouped by symbol class: thread row ty owns the columns with sym % 8 == ty (no two threads ever touch the
+  // same accumulator, rows are added in ascending s: deterministic).  Each 32-thread row first builds the ordered
+  // list of its rows in LDS (ballot compaction), then sweeps only those -- S/8 iterations instead of S.
+  unsigned short* slist = reinterpret_cast<unsigned short*>(csx + 8 * TT) + (size_t)ty * S;
+  int cnt = 0;
+  {
+    const int hshift = 32 * (ty & 1);   // which half of the wave this thread row is
+    for (int s0 = 0; s0 < S; s0 += 32) {
+      const int s = s0 + tx;
+      const bool mine = s < S && (symb[s] & 7) == ty;
+      const unsigned m32 = (unsigned)(__ballot(mine) >> hshift);
+      if (mine) slist[cnt + __popc(m32 & ((1u << tx) - 1u))] = (unsigned short)s;
+      cnt += __popc(m32);
     }
   }
-  for (int s = ty; s <= S; s += 8)
-    if (tok) cs += gpy[((size_t)b * (S + 1) + s) * T + t];
+  __syncthreads();
+  float cs = 0.0f, cx = 0.0f;
+  if (xok) {
+    const float* gcol = gpx + (size_t)b * S * T1 + t;
+    int i = 0;
+    for (; i + 3 < cnt; i += 4) {
+      const int s_0 = slist[i], s_1 = slist[i + 1], s_2 = slist[i + 2], s_3 = slist[i + 3];
+      const float g0 = gcol[(size_t)s_0 * T1], g1 = gcol[(size_t)s_1 * T1];
+      const float g2 = gcol[(size_t)s_2 * T1], g3 = gcol[(size_t)s_3 * T1];
+      acc[tx * ld + symb[s_0]] += g0; cx += g0;
+      acc[tx * ld + symb[s_1]] += g1; cx += g1;
+      acc[tx * ld + symb[s_2]] += g2; cx += g2;
+      acc[tx * ld + symb[s_3]] += g3; cx += g3;
+    }
+    for (; i < cnt; ++i) {
+      const int s_0 = slist[i];
+      const float g0 = gcol[(size_t)s_0 * T1];
+      acc[tx * ld + symb[s_0]] += g0; cx += g0;
+    }
+  }
+  if (tok) {
+    const float* ycol = gpy + (size_t)b * (S + 1) * T + t;
+#pragma unroll 4
+    for (int s = ty; s <= S; s += 8) cs += ycol[(size_t)s * T];
+  }
   csy[ty * TT + tx] = cs;
   csx[ty * TT + tx] = cx;
   __syncthreads();
@@ -313,7 +360,7 @@ int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols
                         double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog,
                         float cs, float ls, float as, float* px, float* py, int B, int T, int S, int C, int modified,
                         hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)TT * (C + 1);
+  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 6 * (size_t)(S + 1));
   int rc = tile_lds_ok(lds, "simple_logprobs_fwd");
   if (rc != FTR_OK) return rc;
   const int T1 = modified ? T : T + 1;
@@ -340,7 +387,8 @@ int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp
                            const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec,
                            const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C,
                            int modified, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 16 * TT);
+  if (S > 65535) { set_error("simple_logprobs_bwd_am: S = %d > 65535 is not supported", S); return FTR_ERR_UNSUPPORTED; }
+  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 16 * TT) + sizeof(unsigned short) * 8 * (size_t)S;
   int rc = tile_lds_ok(lds, "simple_logprobs_bwd_am");
   if (rc != FTR_OK) return rc;
   const dim3 grid((T + TT - 1) / TT, B);

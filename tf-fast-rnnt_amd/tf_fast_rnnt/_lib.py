@@ -34,6 +34,8 @@ _SIGNATURES = {
     "ftr_prune_ranges_i32": (_i, [_c_fp, _c_fp, _c_ip, _c_ip, _c_ip, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _c_st]),
     "ftr_do_pruning_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_do_pruning_bwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_do_pruning_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
+    "ftr_do_pruning_bwd_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
     "ftr_pruned_logprobs_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_logprobs_bwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_rowmax_exp_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),

@@ -398,9 +398,11 @@ class _DoPruning(torch.autograd.Function):
         g_am_p = g_am_p.contiguous(); g_lm_p = g_lm_p.contiguous()
         g_am = torch.empty((B, T, C), dtype=g_am_p.dtype, device=g_am_p.device)     # broadcast <-> sum over s_range
         g_lm = torch.empty((B, S1, C), dtype=g_lm_p.dtype, device=g_lm_p.device)    # gather    <-> segment sum
+        ws_bytes = int(_lib.lib().ftr_do_pruning_bwd_workspace_bytes(B, T, S1, C, r))
+        ws = torch.empty(((ws_bytes + 3) // 4,), dtype=torch.float32, device=g_am_p.device) if ws_bytes else None
         with torch.cuda.device(g_am_p.device):
-            _lib.call("ftr_do_pruning_bwd_f32", _ptr(g_am_p), _ptr(g_lm_p), _ptr(ranges), _ptr(g_am), _ptr(g_lm),
-                      B, T, S1, C, r, _stream_ptr(g_am_p))
+            _lib.call("ftr_do_pruning_bwd_ws_f32", _ptr(g_am_p), _ptr(g_lm_p), _ptr(ranges), _ptr(g_am), _ptr(g_lm),
+                      B, T, S1, C, r, _ptr(ws), ws_bytes, _stream_ptr(g_am_p))
         return g_am, g_lm, None
 
 
