@@ -40,10 +40,11 @@ const char* ftr_package_version(void);
 /* Thread-local description of the last non-success return on this thread ("" if none). */
 const char* ftr_last_error(void);
 /* Selects the mutual-information kernel family: 0 = "wavefront" (default: skewed wave64 DP, one workgroup per
- * 64-row band, bands chained through tagged granules; mi_wave_chain.hip), 1 = "plain" (one thread per lattice
- * row, reference arithmetic), 2 = "mono", 3 = "duo" (earlier single-workgroup wavefront variants, kept for
- * bisecting: mono up to 1024 rows, duo up to 384).  Also settable with FTR_MI_IMPL=wavefront|plain|mono|duo.
- * Returns the previous value. */
+ * 64-row band, bands chained through tagged granules, the recursion run from both ends of the lattice towards a
+ * cut in the middle; mi_wave_bidir.hip), 1 = "plain" (one thread per lattice row, reference arithmetic),
+ * 2 = "mono", 3 = "duo" (earlier single-workgroup wavefront variants: mono up to 1024 rows, duo up to 384),
+ * 4 = "chain" (the banded wavefront run from one end only; mi_wave_chain.hip) -- 2..4 are kept for bisecting.
+ * Also settable with FTR_MI_IMPL=wavefront|plain|mono|duo|chain.  Returns the previous value. */
 int ftr_set_mi_impl(int impl);
 int ftr_get_mi_impl(void);
 

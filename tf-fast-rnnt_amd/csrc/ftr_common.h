@@ -55,6 +55,9 @@ int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float*
 int mi_chain_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
 int mi_chain_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
 size_t mi_chain_extra_floats(int B, int S, int T);
+int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
+int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
+size_t mi_bidir_workspace_floats(int B, int S, int T);
 int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st);
 int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boundary, int32_t* ranges, int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st);
 int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1, int C, int r, hipStream_t st);

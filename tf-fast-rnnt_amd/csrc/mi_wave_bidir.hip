@@ -1,0 +1,961 @@
+// csrc/mi_wave_bidir.hip -- bidirectional ("meet in the middle") wavefront mutual-information kernels for gfx950,
+// the product path.  Same machinery as mi_wave_chain.hip (one 3-wave workgroup per 64-row band, bands chained
+// through 8-byte granules, time-skewed wavefront, log2 domain), but the serial dependency chain -- the one thing
+// that bounds this kernel -- is cut in half:
+//
+//   forward launch, 2 * B * NB workgroups
+//     dir 0 "alpha":  p(s,t) from the origin (s_begin,t_begin) up to the CUT, the anti-diagonal
+//                     (s - s_begin) + (t - t_begin) = jm (regular) / the column t - t_begin = jm (modified), jm = D / 2;
+//     dir 1 "beta":   q(s,t) = log-prob of reaching (s_end,t_end) from (s,t), from the end cell back to the same cut.
+//                     In reversed coordinates r = s_end - s, c = t_end - t this is the SAME recursion with
+//                     X(r,c) = px[s,t], Y(r,c) = py[s,t]  (reference recursion: mutual_information_cuda.cu:149-239,
+//                     mirrored), so the compute and COMM waves are shared and only the IO wave's addressing differs.
+//     Both store, per cell, the split ratio G = sigmoid(a - b) of the two incoming terms (alpha: what fraction of
+//     p(s,t) arrived through px; beta: what fraction of q(s,t) leaves through px) in their own lattice, and the
+//     values on the cut in `pmid`.
+//   mid kernel, B workgroups:  ans = logsumexp over the cut of p + q;  occ = exp(p + q - ans) = the occupancy of
+//     every cut cell (every path crosses the cut exactly once).
+//   flow launch, 2 * B * NB workgroups (the backward pass, cf. mutual_information_cuda.cu:452-715): the occupancy
+//     is injected on the cut and propagated outwards with the stored ratios -- dir 0 from the cut back to the origin
+//     (writes the transitions that end on or before the cut), dir 1 from the cut forward to the end cell (writes the
+//     transitions that start on or after it).  No exp/log, mass is conserved exactly, px_grad / py_grad are the
+//     per-transition flows.
+// Each chain is (S+T)/2 steps long instead of S+T, for the forward and for the backward pass.
+//
+// Walk coordinates (r, c): lane = r - 64 * band, step j = c + SKEW * r.  "FWD addressing" = walk coordinates are
+// (s - s_begin, t - t_begin); "REV addressing" = (s_end - s, t_end - t).  Forward alpha and flow beta use FWD,
+// forward beta and flow alpha use REV.
+//
+// Workspace ("p" in the C ABI), floats:  [ G_alpha lattice | G_beta lattice | pmid 2*B*(S+1) | occ B*(S+1) | pad |
+//                                          granules 2 * B * NB * Tg * 8 bytes ].
+#include "ftr_common.h"
+#include "mi_wave_common.h"
+#include <type_traits>
+
+namespace ftr {
+using namespace wavecfg;
+namespace {
+
+constexpr int NPFC = 3;          // chunks in flight in the IO wave's registers
+constexpr int kMaxSpin = 400000; // polls of ~1 us before a band gives up (never reached unless a producer died)
+typedef unsigned long long u64;
+
+__host__ __device__ inline int granules_per_band(int T, int modified) {
+  const int nchunks = (T + 1 + (modified ? 0 : 63) + CH - 1) / CH;
+  return CH * (nchunks + 1);
+}
+__host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
+  size_t L = (size_t)B * (S + 1) * (T + 1);
+  return (L + 3) & ~(size_t)3;
+}
+
+// COMM wave helpers (see mi_wave_chain.hip) -----------------------------------------------------------------
+__device__ __forceinline__ void comm_publish(const float* out_ring, u64* gran_out, int m, int lane) {
+  if (lane < CH) {
+    const float v = out_ring[(CH * m + lane) & (RINGN - 1)];
+    const u64 g = ((u64)(unsigned)(m + 1) << 32) | (u64)__float_as_uint(v);
+    __hip_atomic_store(gran_out + CH * m + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
+  return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool comm_import(float* in_ring, const u64* gran_in, int m, int lane, u64 g) {
+  const int idx = CH * m + (lane & (CH - 1));
+  for (int spins = 0;; ++spins) {
+    const bool ok = (unsigned)(g >> 32) == (unsigned)(m + 1);
+    if (__all(ok)) break;                 // wave-uniform exit
+    if (spins >= kMaxSpin) return false;  // wave-uniform (spins is uniform)
+    __builtin_amdgcn_s_sleep(24);
+    g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (lane < CH) in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
+  return true;
+}
+__device__ __forceinline__ f4 rev4(const f4 t) {
+  f4 v;
+  v[0] = t[3]; v[1] = t[2]; v[2] = t[1]; v[3] = t[0];
+  return v;
+}
+
+// the cut: D = last walk step of the lattice, jm = D / 2 in alpha coordinates
+struct Cut { int D, jm; };
+template <bool MOD>
+__device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
+  Cut c;
+  c.D = (MOD ? 0 : (Sn - 1)) + (Tn - 1);
+  c.jm = c.D >> 1;
+  return c;
+}
+
+#define FTR_TX(k) (lds + ((k) & 1) * TILE_F4)
+#define FTR_TY(k) (lds + (2 + ((k) & 1)) * TILE_F4)
+#define FTR_TD(k) (lds + (4 + ((k) & 1)) * TILE_F4)
+
+// ------------------------------------------------------------------------------------------------- forward
+// One direction of one band.  REVM selects the IO wave's addressing (see the header).
+template <bool MOD, bool REVM>
+__device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float* __restrict__ px,
+                                               const float* __restrict__ py, const Bound bd, float* __restrict__ wsb,
+                                               u64* __restrict__ gran_b, float* __restrict__ pmid_b, int b, int w,
+                                               int Tg, int S, int T, int jstop) {
+  constexpr int SKEW = MOD ? 0 : 1;
+  constexpr int NOFF = MOD ? 1 : 0;
+  constexpr int NPF = NPFC;
+  constexpr int LOOK = MOD ? 1 : 5;  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK
+  constexpr int PRE = NPF + 1;       // IO pipeline warm-up slots in front of chunk 0
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO, 2 COMM
+  const int T1 = MOD ? T : T + 1;
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  const int NWact = (Sn + 63) >> 6;
+
+  f4* lds = reinterpret_cast<f4*>(smem);
+  float* in_ring = reinterpret_cast<float*>(lds + 6 * TILE_F4);   // values of the band above (row row0-1)
+  float* out_ring = in_ring + RINGN;                              // this band's lane 63
+  for (int i = threadIdx.x; i < 2 * RINGN; i += blockDim.x) in_ring[i] = kNeg;
+  __syncthreads();
+
+  // Bands step in LOCAL walk steps (lane l of band w is on column j - SKEW * l at local step j): the cut, given in
+  // global steps, is at local step jl.  A band whose rows all lie beyond the cut has nothing to compute.
+  const int jl = jstop - SKEW * 64 * w;
+  if (jl < 0) {
+    if (wid == 0 && 64 * w + lane < Sn) pmid_b[64 * w + lane] = kNeg;
+    return;
+  }
+  // A band never steps past its own last column (local step Tn - 1 + 63 * SKEW): if the cut lies beyond that, none
+  // of the band's rows has a cell on the cut, but the band still feeds the bands below.
+  const int nchunks_nat = (Tn + 63 * SKEW + CH - 1) / CH;
+  if (jl >= CH * nchunks_nat && wid == 0 && 64 * w + lane < Sn) pmid_b[64 * w + lane] = kNeg;
+  const int klast = min(jl / CH + 1, nchunks_nat);   // chunks [0, klast): local steps 0 .. jl (and the rest of that chunk)
+  const int klast_up = MOD ? klast : min((jl + 64) / CH + 1, nchunks_nat);   // what the band above computes (and publishes)
+  const int nslots = klast + PRE + 1;
+  const int NIT = (nslots + NPF - 1) / NPF;
+  const int base = -PRE;  // kc = base + gg
+
+  if (wid == 0) {
+    // ======================================================================= COMPUTE wave
+    const f4* ring_in = reinterpret_cast<const f4*>(in_ring);
+    f4* ring_out = reinterpret_cast<f4*>(out_ring);
+    float pcur = (w == 0 && lane == 0) ? 0.0f : kNeg;  // origin trick: p[origin] = 0 + (Y := 0)
+    float ecarry = kNeg;
+    const float lane0 = (lane == 0) ? 1.0f : 0.0f;
+
+    auto compute_chunk = [&](int k) {
+      const f4* cX = FTR_TX(k);
+      const f4* cY = FTR_TY(k);
+      f4* cD = FTR_TD(k);
+      f4 Xn = cX[lane], Yn = cY[lane];
+      f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int j0 = CH * k + 4 * q;
+        const f4 X4 = Xn, Y4 = Yn, E4 = En;
+        if (q + 1 < NQ) {  // next quad's operands are fetched while this quad's chain runs
+          Xn = cX[(q + 1) * PLANE + lane];
+          Yn = cY[(q + 1) * PLANE + lane];
+          En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
+        }
+        f4 XE;
+        XE[0] = __builtin_fmaf(lane0, ecarry, X4[0]); XE[1] = __builtin_fmaf(lane0, E4[0], X4[1]);
+        XE[2] = __builtin_fmaf(lane0, E4[1], X4[2]);  XE[3] = __builtin_fmaf(lane0, E4[2], X4[3]);
+        f4 V4, P4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pcur), 0x138, 0xf, 0xf, true));
+          const float a = up + XE[e];
+          const float c = pcur + Y4[e];
+          const float d = a - c;
+          const float mx = fmaxf(a, c);
+          const float ex = __builtin_amdgcn_exp2f(-__builtin_fabsf(d));
+          pcur = mx + __builtin_amdgcn_logf(1.0f + ex);
+          V4[e] = __builtin_copysignf(ex, d);  // exp2(-|d|) with the sign of d: all the IO wave needs for G
+          P4[e] = pcur;
+        }
+        ecarry = E4[3];
+        cD[q * PLANE + lane] = V4;
+        if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = P4;
+        if ((jl >> 2) == (j0 >> 2)) {  // wave-uniform: this band's values on the cut
+          const int e = jl & 3;
+          const float v = (e == 0) ? P4[0] : (e == 1) ? P4[1] : (e == 2) ? P4[2] : P4[3];
+          if (64 * w + lane < Sn) pmid_b[64 * w + lane] = v;
+        }
+      }
+    };
+
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int kc = base + gg;
+      if (kc >= 0 && kc < klast) {
+        if (kc == 0) ecarry = in_ring[RINGN - 1];
+        compute_chunk(kc);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  if (wid == 2) {
+    // ======================================================================= COMM wave
+    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;        // read by band w+1
+    const u64* gran_in = gran_b + (size_t)w * Tg;         // written by band w-1
+    const bool has_up = w > 0, has_down = w + 1 < NWact;
+    bool dead = false;
+    u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int kc = base + gg;
+      if (has_down && kc - 1 >= 0 && kc - 1 < klast) comm_publish(out_ring, gran_out, kc - 1, lane);
+      const int m = kc + LOOK;
+      u64 g_next = 0;
+      if (has_up && !dead && m + 1 >= 0 && m + 1 < klast_up) g_next = comm_peek(gran_in, m + 1, lane);
+      if (has_up && !dead && m >= 0 && m < klast_up) {
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {   // producer never showed up: poison, stop polling
+          dead = true;
+          in_ring[lane] = __builtin_nanf("");
+        }
+      }
+      g_cur = g_next;
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ========================================================================= IO wave
+  const int row0 = 64 * w;
+  // staging geometry of this lane: in load/store instruction m it handles tile row 16m + (lane>>2), quad (lane&3)
+  const int frow = lane >> 2, fq = lane & 3;
+  f4 rx[NPF][4], ry[NPF][4];
+
+  auto load_general = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      const int c0 = CH * k + 4 * fq - SKEW * row;  // walk column of the quad's first step
+      f4 vx = {kNeg, kNeg, kNeg, kNeg}, vy = {kNeg, kNeg, kNeg, kNeg};
+      if (r < Sn) {
+        if (!REVM) {
+          if (r >= 1) {  // px[s-1][t + toff], toff = -1 for modified
+            const int cx = MOD ? c0 - 1 : c0;
+            const ptrdiff_t o = (ptrdiff_t)(bd.sb + r - 1) * T1 + bd.tb + cx;
+            if (cx >= 0 && c0 + 3 < Tn) {
+              vx = *reinterpret_cast<const f4u*>(px + o);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (cx + e >= 0 && c0 + e < Tn) vx[e] = px[o + e];
+            }
+          }
+          {  // py[s][t-1]
+            const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * T + bd.tb + c0 - 1;
+            if (c0 >= 1 && c0 + 3 < Tn) {
+              vy = *reinterpret_cast<const f4u*>(py + o);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (c0 + e >= 1 && c0 + e < Tn) vy[e] = py[o + e];
+            }
+          }
+        } else {
+          // element e is walk column c0+e, i.e. t = te - c0 - e: memory order is the reverse of e
+          if (r >= 1) {  // px[s][t], s = se - r <= se - 1; modified: t <= te - 1
+            const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * T1 + bd.te - c0 - 3;
+            if (c0 >= NOFF && c0 + 3 < Tn) {
+              vx = rev4(*reinterpret_cast<const f4u*>(px + lo));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (c0 + e >= NOFF && c0 + e < Tn) vx[e] = px[lo + 3 - e];
+            }
+          }
+          {  // py[s][t], t <= te - 1
+            const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * T + bd.te - c0 - 3;
+            if (c0 >= 1 && c0 + 3 < Tn) {
+              vy = rev4(*reinterpret_cast<const f4u*>(py + lo));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (c0 + e >= 1 && c0 + e < Tn) vy[e] = py[lo + 3 - e];
+            }
+          }
+        }
+      }
+      x[m] = vx;
+      y[m] = vy;
+    }
+  };
+  // kk = chunk being parked.  The origin cell (chunk 0, tile row 0, quad 0, element 0 of band 0) gets Y := 0 so that
+  // p = logadd(-inf, pcur(0) + 0) = 0 falls out of the recursion.
+  auto park = [&](int kk, const f4 (&x)[4], const f4 (&y)[4]) {
+    f4* dX = FTR_TX(kk);
+    f4* dY = FTR_TY(kk);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      f4 xs, ys;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xs[e] = fmaxf(x[m][e] * kLog2e, kNeg);  // log2 domain; -inf (and nan) -> kNeg
+        ys[e] = fmaxf(y[m][e] * kLog2e, kNeg);
+      }
+      if (m == 0 && kk == 0 && w == 0 && lane == 0) ys[0] = 0.0f;
+      dX[fq * PLANE + row] = xs;
+      dY[fq * PLANE + row] = ys;
+    }
+  };
+  // G = sigmoid(d) from v = copysign(exp2(-|d|), d):  d >= 0 -> 1/(1+e),  d < 0 -> e/(1+e)
+  auto to_G = [&](const f4& v) {
+    f4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ve = v[e];  // scalar copy first: bit_cast applied to a vector-element lvalue reads element 0
+      const float ea = __builtin_fabsf(ve);
+      const float rc = __builtin_amdgcn_rcpf(1.0f + ea);
+      g[e] = (__float_as_int(ve) < 0) ? ea * rc : rc;  // sign BIT: -0.0 (e underflowed) is "d < 0"
+    }
+    return g;
+  };
+  auto drain_general = [&](int k) {
+    const f4* sD = FTR_TD(k);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      if (r < Sn) {
+        const int c0 = CH * k + 4 * fq - SKEW * row;
+        const f4 g = to_G(sD[fq * PLANE + row]);
+        if (!REVM) {
+          const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
+          if (c0 >= 0 && c0 + 3 < Tn) {
+            *reinterpret_cast<f4u*>(wsb + o) = g;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= 0 && c0 + e < Tn) wsb[o + e] = g[e];
+          }
+        } else {
+          const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
+          if (c0 >= 0 && c0 + 3 < Tn) {
+            *reinterpret_cast<f4u*>(wsb + lo) = rev4(g);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= 0 && c0 + e < Tn) wsb[lo + 3 - e] = g[e];
+          }
+        }
+      }
+    }
+  };
+
+  // ---- interior ("fast") chunks: every quad of every lane-row lies inside [1, Tn) in columns, so loads and
+  // stores are plain 16-byte accesses with no per-element guards and no divergent control flow.  Rows
+  // beyond the utterance are clamped to a valid row: what they compute never reaches a valid row (data
+  // only moves from row r-1 to row r) and is never stored.  Row 0's X is neutralised by the ring's -inf.
+  int offX[4], offY[4], offG[4];
+  bool rvalid[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = 16 * m + frow;
+    const int r = row0 + row;
+    const int cq = 4 * fq - SKEW * row;
+    if (!REVM) {
+      const int rxc = min(max(r - 1, 0), max(Sn - 2, 0));   // px row s-1 (clamped)
+      const int ryc = min(r, Sn - 1);                       // py row s   (clamped)
+      offX[m] = (bd.sb + rxc) * T1 + bd.tb + cq + (MOD ? -1 : 0);
+      offY[m] = (bd.sb + ryc) * T + bd.tb + cq - 1;
+      offG[m] = (bd.sb + r) * (T + 1) + bd.tb + cq;
+    } else {
+      const int rxc = min(max(r, 1), max(Sn - 1, 1));       // px row s = se - r, r in [1, Sn-1] (clamped)
+      const int ryc = min(r, Sn - 1);
+      offX[m] = (bd.se - rxc) * T1 + bd.te - cq - 3;
+      offY[m] = (bd.se - ryc) * T + bd.te - cq - 3;
+      offG[m] = (bd.se - r) * (T + 1) + bd.te - cq - 3;
+    }
+    rvalid[m] = r < Sn;
+  }
+  auto load_fast = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
+    if (!REVM) {
+      const float* px_k = px + CH * k;   // wave-uniform part of the address
+      const float* py_k = py + CH * k;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        x[m] = *reinterpret_cast<const f4u*>(px_k + offX[m]);
+        y[m] = *reinterpret_cast<const f4u*>(py_k + offY[m]);
+      }
+    } else {
+      const float* px_k = px - CH * k;
+      const float* py_k = py - CH * k;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        x[m] = rev4(*reinterpret_cast<const f4u*>(px_k + offX[m]));
+        y[m] = rev4(*reinterpret_cast<const f4u*>(py_k + offY[m]));
+      }
+    }
+  };
+  auto drain_fast = [&](int k) {
+    const f4* sD = FTR_TD(k);
+    float* ws_k = REVM ? wsb - CH * k : wsb + CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f4 g = to_G(sD[fq * PLANE + 16 * m + frow]);
+      if (rvalid[m]) *reinterpret_cast<f4u*>(ws_k + offG[m]) = REVM ? rev4(g) : g;
+    }
+  };
+
+  auto slot_general = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
+    if (kc + 1 >= 0 && kc + 1 < klast) park(kc + 1, x, y);
+    if (kc - 1 >= 0 && kc - 1 < klast) drain_general(kc - 1);
+    if (kc + 1 + NPF >= 0 && kc + 1 + NPF < klast) load_general(kc + 1 + NPF, x, y);
+    __syncthreads();
+  };
+  auto slot_fast = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
+    park(kc + 1, x, y);         // loads of chunk kc+1 were issued NPF slots ago
+    drain_fast(kc - 1);
+    load_fast(kc + 1 + NPF, x, y);
+    __syncthreads();
+  };
+
+  // Fast slot kc: the drained chunk kc-1 and the loaded chunk kc+1+NPF are interior and inside [0, klast).
+  const int K0 = MOD ? 1 : 4;                                      // 16k - 63*SKEW >= 1
+  const int K1 = min((Tn >= CH) ? (Tn - CH) / CH + 1 : 0, klast);  // 16k + 15 < Tn
+  const int KF0 = K0 + 1, KF1 = (Sn >= 2) ? K1 - 1 - NPF : 0;      // fast slots: KF0 <= kc < KF1
+  int it1 = (KF0 - base + NPF - 1) / NPF;                // first iteration whose first slot has kc >= KF0
+  int it2 = (KF1 - base) / NPF;                          // first iteration whose last slot has kc >= KF1
+  it1 = min(max(it1, 0), NIT);
+  it2 = min(max(it2, it1), NIT);
+
+  int it = 0;
+  for (; it < it1; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+  }
+  if (it < it2) {
+    __builtin_amdgcn_s_waitcnt(kVmcnt0);  // nothing pending when the steady-state loop is entered
+    for (; it < it2; ++it) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) slot_fast(base + NPF * it + u, rx[u], ry[u]);
+    }
+  }
+  for (; it < NIT; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+  }
+}
+
+#undef FTR_TX
+#undef FTR_TY
+#undef FTR_TD
+
+template <bool MOD>
+__global__ __launch_bounds__(192) void mi_bidir_fwd_kernel(
+    const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
+    float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, int B, int NB, int Tg, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b2 = blockIdx.x % (2 * B);           // band-major block ids: producers are dispatched first
+  const int w = blockIdx.x / (2 * B);            // band of 64 walk rows
+  const int dir = b2 / B, b = b2 - dir * B;
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  if (Sn <= 0 || Tn <= 0) return;                // the mid kernel reports ans = 0
+  if (w >= ((Sn + 63) >> 6)) return;             // bands past the utterance's last row: nobody waits for them
+  const Cut cut = make_cut<MOD>(Sn, Tn);
+  const int T1 = MOD ? T : T + 1;
+  const float* pxb = px + (size_t)b * S * T1;
+  const float* pyb = py + (size_t)b * (S + 1) * T;
+  float* wsb = ws + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
+  u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
+  float* pmid_b = pmid + ((size_t)dir * B + b) * (S + 1);
+  if (dir == 0) bidir_fwd_body<MOD, false>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, b, w, Tg, S, T, cut.jm);
+  else bidir_fwd_body<MOD, true>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, b, w, Tg, S, T, cut.D - cut.jm);
+}
+
+// ----------------------------------------------------------------------------------------------------- mid
+// ans[b] = logsumexp over the cut of p + q (log2 domain in, natural log out); occ[b][s - s_begin] = the occupancy
+// of the cut cell in lattice row s.  Alpha lane r and beta lane Sn-1-r hold the same cell.
+__global__ __launch_bounds__(256) void mi_bidir_mid_kernel(const int32_t* __restrict__ boundary,
+                                                           const float* __restrict__ pmid, float* __restrict__ occ,
+                                                           float* __restrict__ ans, int B, int S, int T) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  if (Sn <= 0 || Tn <= 0) { if (threadIdx.x == 0) ans[b] = 0.0f; return; }
+  const float* pa = pmid + (size_t)b * (S + 1);
+  const float* pb = pmid + ((size_t)B + b) * (S + 1);
+  float m = -INFINITY;
+  for (int r = threadIdx.x; r < Sn; r += 256) m = fmaxf(m, pa[r] + pb[Sn - 1 - r]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f(pa[r] + pb[Sn - 1 - r] - m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float total = m + log2f(sum);
+  const bool dead = !(total > kNegThresh);      // no path (or nan): ans = -inf, no flow
+  if (threadIdx.x == 0) ans[b] = dead ? -INFINITY : total * kLn2;
+  float* ob = occ + (size_t)b * (S + 1);
+  // normalised with the very sum they add up to (not with exp2(-total)): the injected occupancies sum to 1 to
+  // rounding, whatever the magnitude of p + q (thousands on long utterances)
+  const float inv = 1.0f / sum;
+  for (int r = threadIdx.x; r < Sn; r += 256) ob[r] = dead ? 0.0f : exp2f(pa[r] + pb[Sn - 1 - r] - m) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------- flow
+#define FTR_TG(k) (lds + ((k) & 1) * TILE_F4)
+#define FTR_TPX(k) (lds + (2 + ((k) & 1)) * TILE_F4)
+#define FTR_TPY(k) (lds + (4 + ((k) & 1)) * TILE_F4)
+
+// One direction of one band of the backward pass.  REVM = true: from the cut back to the origin (alpha half),
+// REVM = false: from the cut forward to the end cell (beta half).  jinj = walk step of the cut in this direction.
+template <bool MOD, bool REVM>
+__device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound bd, const float* __restrict__ wsb,
+                                                u64* __restrict__ gran_b, const float* __restrict__ occ_b,
+                                                float* __restrict__ pxg, float* __restrict__ pyg,
+                                                float* __restrict__ ans_grad, int overwrite, int b, int w, int Tg,
+                                                int S, int T, int jinj) {
+  constexpr int SKEW = MOD ? 0 : 1;
+  constexpr int NOFF = MOD ? 1 : 0;
+  constexpr int NPF = NPFC;
+  constexpr int LOOK = MOD ? 1 : 5;
+  constexpr int PRE = NPF + 1;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO, 2 COMM
+  const int T1 = MOD ? T : T + 1;
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  const int NWact = (Sn + 63) >> 6;
+
+  f4* lds = reinterpret_cast<f4*>(smem);
+  float* in_ring = reinterpret_cast<float*>(lds + 6 * TILE_F4);
+  float* out_ring = in_ring + RINGN;
+  for (int i = threadIdx.x; i < 2 * RINGN; i += blockDim.x) in_ring[i] = 0.0f;
+  __syncthreads();
+
+  const int nchunks = (Tn + 63 * SKEW + CH - 1) / CH;
+  // band-local walk step of the cut (see the forward body); negative: every cell of this band lies past the cut,
+  // the band starts at its first step with nothing injected and receives its flow from the band above.
+  const int jli = jinj - SKEW * 64 * w;
+  const int kfirst = max(jli, 0) / CH;                // chunks [kfirst, nchunks)
+  const int kfirst_up = MOD ? kfirst : max(jli + 64, 0) / CH;   // first chunk the band above computes (and publishes)
+  const int nslots = (nchunks - kfirst) + PRE + 1;
+  const int NIT = (nslots + NPF - 1) / NPF;
+  const int base = kfirst - PRE;
+
+  if (wid == 0) {
+    // ======================================================================= COMPUTE wave
+    const f4* ring_in = reinterpret_cast<const f4*>(in_ring);
+    f4* ring_out = reinterpret_cast<f4*>(out_ring);
+    const int wfin = (Sn - 1) >> 6, lfin = (Sn - 1) & 63;
+    // REVM: the walk ends at the origin, where p_grad[s_begin,t_begin] appears (the ans_grad self check)
+    const int jfin = (REVM && w == wfin) ? (Tn - 1 + SKEW * lfin) : -1000;
+    // occupancy of this lane's cut cell, scaled by the incoming gradient
+    float inj = 0.0f;
+    {
+      const int r = 64 * w + lane;
+      if (r < Sn) inj = occ_b[REVM ? (Sn - 1 - r) : r] * ans_grad[b];
+    }
+    float yprev = 0.0f, xprev = 0.0f, ecarry = 0.0f;
+
+    auto compute_chunk = [&](int k, auto inject_tag) {
+      constexpr bool INJ = decltype(inject_tag)::value;
+      const f4* cG = FTR_TG(k);
+      f4* cPX = FTR_TPX(k);
+      f4* cPY = FTR_TPY(k);
+      f4 Gn = cG[lane];
+      f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int j0 = CH * k + 4 * q;
+        const f4 G4 = Gn, E4 = En;
+        if (q + 1 < NQ) {
+          Gn = cG[(q + 1) * PLANE + lane];
+          En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
+        }
+        f4 XO4, PX4, PY4, PG4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ev = (e == 0) ? ecarry : E4[e - 1];
+          const float xin = dpp_wave_shr1(ev, xprev);
+          float pg = xin + yprev;
+          if (INJ && j0 + e == jli) pg += inj;    // the cut: nothing has flowed yet, the occupancy enters here
+          PX4[e] = xin;    // flow through the px transition between this cell and its walk predecessor row
+          PY4[e] = yprev;  // flow through the py transition between this cell and its walk predecessor column
+          PG4[e] = pg;     // occupancy of the cell
+          // steps in front of the cut (first chunk only) lie in the other half: their ratios were never computed
+          // (uninitialised memory, possibly NaN), so the zero flow there is forced rather than multiplied
+          const bool pre = INJ && (j0 + e < jli);
+          xprev = pre ? 0.0f : pg * G4[e];
+          yprev = pre ? 0.0f : pg - xprev;
+          XO4[e] = xprev;
+        }
+        ecarry = E4[3];
+        cPX[q * PLANE + lane] = PX4;
+        cPY[q * PLANE + lane] = PY4;
+        if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = XO4;
+        if (overwrite && (jfin >> 2) == (j0 >> 2)) {
+          const int e = jfin & 3;
+          const float v = (e == 0) ? PG4[0] : (e == 1) ? PG4[1] : (e == 2) ? PG4[2] : PG4[3];
+          if (lane == lfin) ans_grad[b] = v;
+        }
+      }
+    };
+
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int kc = base + gg;
+      if (kc >= kfirst && kc < nchunks) {
+        if (kc == kfirst) {
+          ecarry = in_ring[(CH * kfirst - 1) & (RINGN - 1)];
+          compute_chunk(kc, std::true_type{});
+        } else {
+          compute_chunk(kc, std::false_type{});
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  if (wid == 2) {
+    // ======================================================================= COMM wave
+    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
+    const u64* gran_in = gran_b + (size_t)w * Tg;
+    const bool has_up = w > 0, has_down = w + 1 < NWact;
+    bool dead = false;
+    u64 g_cur = 0;
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int kc = base + gg;
+      if (has_down && kc - 1 >= kfirst && kc - 1 < nchunks) comm_publish(out_ring, gran_out, kc - 1, lane);
+      const int m = kc + LOOK;
+      u64 g_next = 0;
+      if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
+      if (has_up && !dead && m >= kfirst_up && m < nchunks) {
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {
+          dead = true;
+          in_ring[lane] = __builtin_nanf("");
+        }
+      }
+      g_cur = g_next;
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ========================================================================= IO wave
+  const int row0 = 64 * w;
+  const int frow = lane >> 2, fq = lane & 3;
+  f4 rg[NPF][4];
+
+  auto load_general = [&](int k, f4 (&gq)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      const int c0 = CH * k + 4 * fq - SKEW * row;
+      f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (r < Sn) {
+        if (REVM) {
+          // element e is walk column c0+e, i.e. t = te - c0 - e; memory order is the reverse of e.
+          const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
+          if (c0 >= 0 && c0 + 3 < Tn) {
+            v = rev4(*reinterpret_cast<const f4u*>(wsb + lo));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= 0 && c0 + e < Tn) v[e] = wsb[lo + 3 - e];
+          }
+        } else {
+          const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
+          if (c0 >= 0 && c0 + 3 < Tn) {
+            v = *reinterpret_cast<const f4u*>(wsb + o);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e >= 0 && c0 + e < Tn) v[e] = wsb[o + e];
+          }
+        }
+      }
+      gq[m] = v;
+    }
+  };
+  auto park = [&](int kk, const f4 (&gq)[4]) {
+    f4* dG = FTR_TG(kk);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dG[fq * PLANE + 16 * m + frow] = gq[m];
+  };
+  // Steps up to and including the cut (local walk step <= jli) belong to the other half and are never written.
+  auto drain_general = [&](int k) {
+    const f4* sX = FTR_TPX(k);
+    const f4* sY = FTR_TPY(k);
+    const int jq = CH * k + 4 * fq;        // walk step of element 0
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = 16 * m + frow;
+      const int r = row0 + row;
+      if (r < Sn) {
+        const int c0 = CH * k + 4 * fq - SKEW * row;
+        const f4 gx = sX[fq * PLANE + row];
+        const f4 gy = sY[fq * PLANE + row];
+        const bool whole = jq > jli;
+        if (REVM) {
+          const int s = bd.se - r;
+          if (r >= 1) {  // px_grad[s][t]: rows s < se; walk columns c in [NOFF, Tn)
+            const ptrdiff_t lo = (ptrdiff_t)s * T1 + bd.te - c0 - 3;
+            if (whole && c0 >= NOFF && c0 + 3 < Tn) {
+              *reinterpret_cast<f4u*>(pxg + lo) = rev4(gx);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (jq + e > jli && c0 + e >= NOFF && c0 + e < Tn) pxg[lo + 3 - e] = gx[e];
+            }
+          }
+          {  // py_grad[s][t]: columns t < te  <=>  c >= 1
+            const ptrdiff_t lo = (ptrdiff_t)s * T + bd.te - c0 - 3;
+            if (whole && c0 >= 1 && c0 + 3 < Tn) {
+              *reinterpret_cast<f4u*>(pyg + lo) = rev4(gy);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (jq + e > jli && c0 + e >= 1 && c0 + e < Tn) pyg[lo + 3 - e] = gy[e];
+            }
+          }
+        } else {
+          if (r >= 1) {  // px_grad[s-1][t + toff]: the transition INTO this cell from the row below
+            const int cx = MOD ? c0 - 1 : c0;
+            const ptrdiff_t o = (ptrdiff_t)(bd.sb + r - 1) * T1 + bd.tb + cx;
+            if (whole && cx >= 0 && c0 + 3 < Tn) {
+              *reinterpret_cast<f4u*>(pxg + o) = gx;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (jq + e > jli && cx + e >= 0 && c0 + e < Tn) pxg[o + e] = gx[e];
+            }
+          }
+          {  // py_grad[s][t-1]: the transition INTO this cell from the previous frame
+            const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * T + bd.tb + c0 - 1;
+            if (whole && c0 >= 1 && c0 + 3 < Tn) {
+              *reinterpret_cast<f4u*>(pyg + o) = gy;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (jq + e > jli && c0 + e >= 1 && c0 + e < Tn) pyg[o + e] = gy[e];
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ---- interior ("fast") chunks, see the forward body.  Clamped rows read some valid row's G: their flow is
+  // exactly zero (nothing is injected into them and nothing flows past the last valid row), so it cannot matter.
+  int offG[4], offPX[4], offPY[4];
+  bool rvalid[4], xvalid[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = 16 * m + frow;
+    const int r = row0 + row;
+    const int cq = 4 * fq - SKEW * row;
+    const int rc = min(r, Sn - 1);
+    if (REVM) {
+      offG[m] = (bd.se - rc) * (T + 1) + bd.te - cq - 3;
+      offPX[m] = (bd.se - r) * T1 + bd.te - cq - 3;
+      offPY[m] = (bd.se - r) * T + bd.te - cq - 3;
+    } else {
+      offG[m] = (bd.sb + rc) * (T + 1) + bd.tb + cq;
+      offPX[m] = (bd.sb + r - 1) * T1 + bd.tb + cq + (MOD ? -1 : 0);
+      offPY[m] = (bd.sb + r) * T + bd.tb + cq - 1;
+    }
+    rvalid[m] = r < Sn;
+    xvalid[m] = r >= 1 && r < Sn;
+  }
+  auto load_fast = [&](int k, f4 (&gq)[4]) {
+    const float* ws_k = REVM ? wsb - CH * k : wsb + CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f4 t4 = *reinterpret_cast<const f4u*>(ws_k + offG[m]);
+      gq[m] = REVM ? rev4(t4) : t4;
+    }
+  };
+  auto drain_fast = [&](int k) {
+    const f4* sX = FTR_TPX(k);
+    const f4* sY = FTR_TPY(k);
+    float* px_k = REVM ? pxg - CH * k : pxg + CH * k;
+    float* py_k = REVM ? pyg - CH * k : pyg + CH * k;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f4 gx = sX[fq * PLANE + 16 * m + frow];
+      const f4 gy = sY[fq * PLANE + 16 * m + frow];
+      if (xvalid[m]) *reinterpret_cast<f4u*>(px_k + offPX[m]) = REVM ? rev4(gx) : gx;
+      if (rvalid[m]) *reinterpret_cast<f4u*>(py_k + offPY[m]) = REVM ? rev4(gy) : gy;
+    }
+  };
+
+  auto slot_general = [&](int kc, f4 (&gq)[4]) {
+    if (kc + 1 >= kfirst && kc + 1 < nchunks) park(kc + 1, gq);
+    if (kc - 1 >= kfirst && kc - 1 < nchunks) drain_general(kc - 1);
+    if (kc + 1 + NPF >= kfirst && kc + 1 + NPF < nchunks) load_general(kc + 1 + NPF, gq);
+    __syncthreads();
+  };
+  auto slot_fast = [&](int kc, f4 (&gq)[4]) {
+    park(kc + 1, gq);
+    drain_fast(kc - 1);
+    load_fast(kc + 1 + NPF, gq);
+    __syncthreads();
+  };
+
+  // fast slot kc: drained chunk kc-1 interior and past the cut's chunk, loaded chunk kc+1+NPF interior
+  const int K0 = max(MOD ? 1 : 4, kfirst + 1);
+  const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;
+  const int KF0 = K0 + 1, KF1 = K1 - 1 - NPF;
+  int it1 = (KF0 - base + NPF - 1) / NPF;
+  int it2 = (KF1 - base) / NPF;
+  it1 = min(max(it1, 0), NIT);
+  it2 = min(max(it2, it1), NIT);
+
+  int it = 0;
+  for (; it < it1; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
+  }
+  if (it < it2) {
+    __builtin_amdgcn_s_waitcnt(kVmcnt0);
+    for (; it < it2; ++it) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) slot_fast(base + NPF * it + u, rg[u]);
+    }
+  }
+  for (; it < NIT; ++it) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
+  }
+}
+
+#undef FTR_TG
+#undef FTR_TPX
+#undef FTR_TPY
+
+template <bool MOD>
+__global__ __launch_bounds__(192) void mi_bidir_flow_kernel(
+    const int32_t* __restrict__ boundary, const float* __restrict__ ws, u64* __restrict__ gran,
+    const float* __restrict__ occ, float* __restrict__ px_grad, float* __restrict__ py_grad,
+    float* __restrict__ ans_grad, int overwrite, int B, int NB, int Tg, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NOFF = MOD ? 1 : 0;
+  const int b2 = blockIdx.x % (2 * B);
+  const int w = blockIdx.x / (2 * B);
+  const int dir = b2 / B, b = b2 - dir * B;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int T1 = MOD ? T : T + 1;
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  float* pxg = px_grad + (size_t)b * S * T1;
+  float* pyg = py_grad + (size_t)b * (S + 1) * T;
+
+  // ---- zeros outside the boundary rectangle (the reference memsets everything first,
+  //      tf_fast_rnnt_op.cc:93-96); the rectangle itself is fully written by the two sweeps.
+  //      dir 0 workgroups fill px_grad, dir 1 workgroups fill py_grad.
+  {
+    const bool empty = (Sn <= 0 || Tn <= 0);
+    const int nwv = 3 * NB;                 // every band's three waves share the fill of this utterance
+    const int fwid = 3 * w + wid;
+    if (dir == 0) {
+      // px_grad is defined on rows [sb, se) x columns [tb, te - NOFF]
+      const int xr0 = empty ? 0 : bd.sb, xr1 = empty ? 0 : bd.se;
+      const int xc0 = bd.tb, xc1 = bd.te - NOFF + 1;
+      for (int s = fwid; s < S; s += nwv) {
+        float* row = pxg + (size_t)s * T1;
+        if (s < xr0 || s >= xr1) {
+          for (int t = lane; t < T1; t += 64) row[t] = 0.0f;
+        } else {
+          for (int t = lane; t < xc0; t += 64) row[t] = 0.0f;
+          for (int t = xc1 + lane; t < T1; t += 64) row[t] = 0.0f;
+        }
+      }
+    } else {
+      // py_grad is defined on rows [sb, se] x columns [tb, te)
+      const int yr0 = empty ? 0 : bd.sb, yr1 = empty ? 0 : bd.se + 1;
+      for (int s = fwid; s < S + 1; s += nwv) {
+        float* row = pyg + (size_t)s * T;
+        if (s < yr0 || s >= yr1) {
+          for (int t = lane; t < T; t += 64) row[t] = 0.0f;
+        } else {
+          for (int t = lane; t < bd.tb; t += 64) row[t] = 0.0f;
+          for (int t = bd.te + lane; t < T; t += 64) row[t] = 0.0f;
+        }
+      }
+    }
+    if (empty) return;
+  }
+  if (w >= ((Sn + 63) >> 6)) return;
+  const Cut cut = make_cut<MOD>(Sn, Tn);
+  const float* wsb = ws + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
+  u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
+  const float* occ_b = occ + (size_t)b * (S + 1);
+  // dir 0 holds the alpha ratios: its flow runs in REV addressing from the cut (walk step D - jm) to the origin;
+  // dir 1 holds the beta ratios: its flow runs in FWD addressing from the cut (walk step jm) to the end cell.
+  if (dir == 0) bidir_flow_body<MOD, true>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, ans_grad, overwrite, b, w, Tg, S, T, cut.D - cut.jm);
+  else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, ans_grad, 0, b, w, Tg, S, T, cut.jm);
+}
+
+inline size_t bidir_lds_bytes() { return (size_t)6 * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }
+
+struct BidirLayout {
+  size_t lat;       // floats per ratio lattice (padded)
+  size_t pmid_off, occ_off, gran_off;   // float offsets
+  int NB, Tg;
+};
+inline BidirLayout bidir_layout(int B, int S, int T, int modified) {
+  BidirLayout l;
+  l.lat = lattice_floats(B, S, T);
+  l.pmid_off = 2 * l.lat;
+  l.occ_off = l.pmid_off + 2 * (size_t)B * (S + 1);
+  size_t g = l.occ_off + (size_t)B * (S + 1);
+  l.gran_off = (g + 3) & ~(size_t)3;
+  l.NB = (S + 1 + 63) / 64;
+  l.Tg = granules_per_band(T, modified);
+  return l;
+}
+
+}  // namespace
+
+// floats of workspace the bidirectional kernels need in total (sized for the regular variant, which needs more)
+size_t mi_bidir_workspace_floats(int B, int S, int T) {
+  const BidirLayout l = bidir_layout(B, S, T, 0);
+  return l.gran_off + 2 * (2 * (size_t)B * l.NB * l.Tg) + 4;
+}
+
+int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S,
+                 int T, int modified, hipStream_t st) {
+  const BidirLayout l = bidir_layout(B, S, T, modified);
+  u64* gran = reinterpret_cast<u64*>(ws + l.gran_off);
+  if ((reinterpret_cast<uintptr_t>(gran) & 7) != 0) { set_error("mi_bidir_fwd: workspace must be 16-byte aligned"); return FTR_ERR_INVALID_ARG; }
+  if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_fwd: memset failed"); return FTR_ERR_LAUNCH; }
+  const size_t lds = bidir_lds_bytes();
+  const dim3 grid(2 * B * l.NB);
+  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(192), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(192), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
+  int rc = check_launch("mi_bidir_fwd");
+  if (rc != FTR_OK) return rc;
+  hipLaunchKernelGGL(mi_bidir_mid_kernel, dim3(B), dim3(256), 0, st, boundary, ws + l.pmid_off, ws + l.occ_off, ans, B, S, T);
+  return check_launch("mi_bidir_mid");
+}
+
+int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad,
+                 int overwrite, int B, int S, int T, int modified, hipStream_t st) {
+  const BidirLayout l = bidir_layout(B, S, T, modified);
+  float* wsm = const_cast<float*>(ws);   // the granule tail of the workspace is scratch
+  u64* gran = reinterpret_cast<u64*>(wsm + l.gran_off);
+  if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_bwd: memset failed"); return FTR_ERR_LAUNCH; }
+  const size_t lds = bidir_lds_bytes();
+  const dim3 grid(2 * B * l.NB);
+  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(192), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(192), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
+  return check_launch("mi_bidir_bwd");
+}
+
+}  // namespace ftr

@@ -359,22 +359,43 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_chunk_kernel(
 __global__ __launch_bounds__(128) void do_pruning_bwd_reduce_kernel(
     const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, const float* __restrict__ partial,
     const int2* __restrict__ meta, float* __restrict__ d_lm, int T, int S1, int C, int r, int nbmax, int nchunks) {
+  extern __shared__ int hits[];    // [nchunks] chunks that hold something for this row, ascending
+  __shared__ int nhits;
   const int s = blockIdx.x, b = blockIdx.y;
+  const int2* mb = meta + (size_t)b * nchunks;
+  if (threadIdx.x < 64) {          // wave 0: 64 chunk descriptors per pass, ballot compaction keeps the order
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cnt = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+      const int ch = c0 + lane;
+      bool hit = false;
+      if (ch < nchunks) {
+        const int2 m = mb[ch];
+        hit = (m.y < 0) || (m.y > 0 && s >= m.x && s < m.x + m.y);
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (hit) hits[cnt + __popcll(mask & lt)] = ch;
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) nhits = cnt;
+  }
+  __syncthreads();
+  const int n = nhits;
   const int n4 = C >> 2;
   for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int2 m = meta[(size_t)b * nchunks + ch];   // wave-uniform
+    for (int i = 0; i < n; ++i) {
+      const int ch = hits[i];
+      const int2 m = mb[ch];
       if (m.y > 0) {
-        const int bin = s - m.x;
-        if (bin >= 0 && bin < m.y)
-          acc += reinterpret_cast<const f4u*>(partial + (((size_t)b * nchunks + ch) * nbmax + bin) * C)[c4];
-      } else if (m.y < 0) {
+        acc += reinterpret_cast<const f4u*>(partial + (((size_t)b * nchunks + ch) * nbmax + (s - m.x)) * C)[c4];
+      } else {
         const int t0 = ch * TCH;
         const int nrows = min(TCH, T - t0) * r;
         const size_t row0 = ((size_t)b * T + t0) * r;
-        for (int i = 0; i < nrows; ++i)
-          if (ranges[row0 + i] == s) acc += reinterpret_cast<const f4u*>(g_lm_p + (row0 + i) * C)[c4];
+        for (int j = 0; j < nrows; ++j)
+          if (ranges[row0 + j] == s) acc += reinterpret_cast<const f4u*>(g_lm_p + (row0 + j) * C)[c4];
       }
     }
     reinterpret_cast<f4u*>(d_lm + ((size_t)b * S1 + s) * C)[c4] = acc;
@@ -493,7 +514,7 @@ int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* r
   }
   int rc = check_launch("do_pruning_bwd_chunk");
   if (rc != FTR_OK) return rc;
-  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(128), 0, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, nbmax, nchunks);
+  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(128), sizeof(int) * (size_t)nchunks, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, nbmax, nchunks);
   return check_launch("do_pruning_bwd_reduce");
 }
 
