@@ -76,6 +76,8 @@ int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32
  *            "wavefront", which keeps p_grad on chip);
  *   ans_grad [B], read; if overwrite_ans_grad it is overwritten with p_grad[b,s_begin,t_begin],
  *            which equals the seed when everything is consistent (mutual_information_cuda.cu:510-514).
+ *            NULL means "all ones" (what the op itself passes, tf_fast_rnnt_op.cc:104-107) without the
+ *            write-back; accepted by the default ("wavefront") family only.
  */
 int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32_t* boundary,
                                    const float* p, float* p_grad, float* px_grad, float* py_grad,
@@ -215,6 +217,31 @@ int ftr_smoothed_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, c
                                      const float* rsx, const float* rsy, int termination_symbol, float direct_scale,
                                      const float* row_term, const float* inv_rowsum, const float* unigram_grad,
                                      float* d_lm, int B, int S, int C, void* stream);
+
+/*
+ * Loss tail and upstream-gradient scaling, so that a whole loss (builder -> recursion -> reduction, and its backward)
+ * runs without framework-side elementwise passes over the lattices.
+ *   ftr_negated_reduce_f32: the batch reduction of rnnt_loss.py:333,544-546,1124-1126,1487-1489 on the device:
+ *     reduction 0 "none": out[b] = -ans[b];  1 "mean": out[0] = -mean(ans);  2 "sum": out[0] = -sum(ans).
+ *     One block, fixed summation tree (deterministic).
+ *   *_scaled_f32: the backward entry points above with the registered gradient of the op (__init__.py:154-162:
+ *     occupancy * upstream gradient) fused in: every incoming lattice gradient of utterance b is multiplied by
+ *     (scale ? scale[b * scale_stride] : 1) * scale_mul while it is read.  scale_stride 0 = one device scalar for the
+ *     whole batch (the gradient of a "sum"/"mean" loss); scale_mul carries the sign and the 1/B of "mean".
+ */
+int ftr_negated_reduce_f32(const float* ans, int B, int reduction, float* out, void* stream);
+int ftr_pruned_logprobs_bwd_scaled_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                       const int32_t* boundary, int termination_symbol, const float* lse,
+                                       const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                       float scale_mul, float* glogits, int B, int T, int S, int C, int r,
+                                       int modified, void* stream);
+int ftr_simple_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                         float scale_mul, const float* prod, const int32_t* boundary, float* W,
+                                         float* rsx, float* rsy, int B, int T, int S, int modified, void* stream);
+int ftr_simple_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                          float scale_mul, const float* damp, const float* am_probs,
+                                          const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                          float* d_am, int B, int T, int S, int C, int modified, void* stream);
 
 /* Hardware self-test used by smoke()/tests: checks on the device that the primitives the wavefront
  * kernels rely on behave as assumed (full-wave DPP shift wave_shr:1 with lane 0 keeping its old value;

@@ -93,7 +93,8 @@ int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32
   clear_error();
   FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_bwd: negative size B=%d S=%d T=%d", B, S, T);
   if (B == 0) return FTR_OK;
-  FTR_REQUIRE(p && py_grad && ans_grad, "mutual_information_bwd: null p/py_grad/ans_grad");
+  FTR_REQUIRE(p && py_grad, "mutual_information_bwd: null p/py_grad");
+  FTR_REQUIRE(ans_grad || mi_impl() == 0, "mutual_information_bwd: ans_grad may be NULL (= ones) only with the default kernel family");
   FTR_REQUIRE(px_grad || S == 0 || (modified && T == 0), "mutual_information_bwd: null px_grad");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
@@ -198,7 +199,7 @@ int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, con
   FTR_REQUIRE(logits && symbols && ranges && lse && gpx && gpy && glogits, "pruned_logprobs_bwd: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return pruned_logprobs_bwd(logits, symbols, ranges, boundary, termination_symbol, lse, gpx, gpy, scale, glogits, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
+  return pruned_logprobs_bwd(logits, symbols, ranges, boundary, termination_symbol, lse, gpx, gpy, Scale{scale, 1, 1.0f}, glogits, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long rows, int C, void* stream) {
@@ -260,7 +261,7 @@ int ftr_simple_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const floa
   FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "simple_logprobs_bwd_w: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_w(gpx, gpy, prod, boundary, W, rsx, rsy, 1.0f, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_w(gpx, gpy, scale_none(), prod, boundary, W, rsx, rsy, 1.0f, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_smoothed_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
@@ -272,7 +273,7 @@ int ftr_smoothed_logprobs_bwd_w_f32(const float* gpx, const float* gpy, const fl
   FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "smoothed_logprobs_bwd_w: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_w(gpx, gpy, prod, boundary, W, rsx, rsy, combined_scale, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_w(gpx, gpy, scale_none(), prod, boundary, W, rsx, rsy, combined_scale, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
@@ -285,7 +286,7 @@ int ftr_simple_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const flo
   FTR_REQUIRE(gpy && damp && am_probs && d_am && (gpx || S == 0) && (symbols || S == 0), "simple_logprobs_bwd_am: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_am(gpx, gpy, damp, am_probs, symbols, boundary, termination_symbol, 1.0f, nullptr, nullptr, 0.0f, nullptr, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_am(gpx, gpy, scale_none(), damp, am_probs, symbols, boundary, termination_symbol, 1.0f, nullptr, nullptr, 0.0f, nullptr, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_smoothed_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
@@ -300,7 +301,7 @@ int ftr_smoothed_logprobs_bwd_am_f32(const float* gpx, const float* gpy, const f
   FTR_REQUIRE(gpy && damp && am_probs && d_am && unigram && am_dot && R && (gpx || S == 0) && (symbols || S == 0), "smoothed_logprobs_bwd_am: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_logprobs_bwd_am(gpx, gpy, damp, am_probs, symbols, boundary, termination_symbol, direct_scale, unigram, am_dot, am_only_scale, R, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+  return simple_logprobs_bwd_am(gpx, gpy, scale_none(), damp, am_probs, symbols, boundary, termination_symbol, direct_scale, unigram, am_dot, am_only_scale, R, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, const int32_t* symbols,
@@ -328,6 +329,59 @@ int ftr_smoothed_logprobs_bwd_lm_f32(const float* dlmp, const float* lm_probs, c
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   return simple_logprobs_bwd_lm(dlmp, lm_probs, symbols, rsx, rsy, termination_symbol, direct_scale, row_term, inv_rowsum, unigram_grad, d_lm, B, S, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_negated_reduce_f32(const float* ans, int B, int reduction, float* out, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 1 && reduction >= 0 && reduction <= 2, "negated_reduce: bad arguments B=%d reduction=%d", B, reduction);
+  FTR_REQUIRE(ans && out, "negated_reduce: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return negated_reduce(ans, B, reduction, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_pruned_logprobs_bwd_scaled_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                       const int32_t* boundary, int termination_symbol, const float* lse,
+                                       const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                       float scale_mul, float* glogits, int B, int T, int S, int C, int r,
+                                       int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1 && r >= 1, "pruned_logprobs_bwd_scaled: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "pruned_logprobs_bwd_scaled: bad termination_symbol");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "pruned_logprobs_bwd_scaled: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(logits && ranges && lse && gpy && glogits && (symbols || S == 0) && (gpx || S == 0), "pruned_logprobs_bwd_scaled: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return pruned_logprobs_bwd(logits, symbols, ranges, boundary, termination_symbol, lse, gpx, gpy, Scale{scale, scale_stride, scale_mul}, glogits, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_simple_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                         float scale_mul, const float* prod, const int32_t* boundary, float* W,
+                                         float* rsx, float* rsy, int B, int T, int S, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0, "simple_logprobs_bwd_w_scaled: bad sizes");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "simple_logprobs_bwd_w_scaled: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "simple_logprobs_bwd_w_scaled: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_w(gpx, gpy, Scale{scale, scale_stride, scale_mul}, prod, boundary, W, rsx, rsy, 1.0f, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_simple_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                          float scale_mul, const float* damp, const float* am_probs,
+                                          const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                          float* d_am, int B, int T, int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "simple_logprobs_bwd_am_scaled: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "simple_logprobs_bwd_am_scaled: bad termination_symbol");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "simple_logprobs_bwd_am_scaled: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && damp && am_probs && d_am && (gpx || S == 0) && (symbols || S == 0), "simple_logprobs_bwd_am_scaled: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_am(gpx, gpy, Scale{scale, scale_stride, scale_mul}, damp, am_probs, symbols, boundary, termination_symbol, 1.0f, nullptr, nullptr, 0.0f, nullptr, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_selftest(void* scratch_dev, void* stream) {

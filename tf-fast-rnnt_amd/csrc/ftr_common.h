@@ -34,6 +34,14 @@ constexpr float kLn2 = 0.6931471805599453f;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Per-utterance factor applied to incoming lattice gradients on the fly: (p ? p[b * stride] : 1) * mul.
+// stride 0 = one scalar for the whole batch (reduction "sum"/"mean"), mul carries the sign and the 1/B of "mean".
+struct Scale {
+  const float* p; int stride; float mul;
+  __device__ __forceinline__ float at(int b) const { return (p ? p[(size_t)b * stride] : 1.0f) * mul; }
+};
+inline Scale scale_none() { return Scale{nullptr, 0, 1.0f}; }
+
 struct Bound { int sb, tb, se, te; };
 __device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ boundary, int b, int S, int T) {
   Bound r;
@@ -65,12 +73,13 @@ size_t do_pruning_bwd_workspace_bytes(int B, int T, int S1, int C, int r);
 int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B, int T, int S1, int C, int r, void* ws, size_t ws_bytes, hipStream_t st);
 int do_pruning_bwd(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B, int T, int S1, int C, int r, hipStream_t st);
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
-int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, const float* scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
+int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, Scale scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, size_t rows, int C, hipStream_t st);
 int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols, const float* prod, const float* am_max, const float* lm_max, const int32_t* boundary, int blank, double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog, float cs, float ls, float as, float* px, float* py, int B, int T, int S, int C, int modified, hipStream_t st);
-int simple_logprobs_bwd_w(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary, float* W, float* rsx, float* rsy, float cs, int B, int T, int S, int modified, hipStream_t st);
-int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
+int simple_logprobs_bwd_w(const float* gpx, const float* gpy, Scale scale, const float* prod, const int32_t* boundary, float* W, float* rsx, float* rsy, float cs, int B, int T, int S, int modified, hipStream_t st);
+int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* damp, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
 int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx, const float* rsy, int blank, float kdir, const float* arow, const float* invsum, const float* gu, float* d_lm, int B, int S, int C, hipStream_t st);
+int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);
 int selftest(hipStream_t st, int* result_dev);
 int debug_stamps(unsigned long long* out16);
 }

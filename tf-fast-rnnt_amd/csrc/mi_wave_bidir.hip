@@ -105,7 +105,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   constexpr int LOOK = MOD ? 1 : 5;  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK
   constexpr int PRE = NPF + 1;       // IO pipeline warm-up slots in front of chunk 0
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO, 2 COMM
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
   const int T1 = MOD ? T : T + 1;
   const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
   const int NWact = (Sn + 63) >> 6;
@@ -159,13 +159,21 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
         f4 XE;
         XE[0] = __builtin_fmaf(lane0, ecarry, X4[0]); XE[1] = __builtin_fmaf(lane0, E4[0], X4[1]);
         XE[2] = __builtin_fmaf(lane0, E4[1], X4[2]);  XE[3] = __builtin_fmaf(lane0, E4[2], X4[3]);
+        const f4 DL = XE - Y4;   // off the chain: d = (up - p) + (X - Y)
         f4 V4, P4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pcur), 0x138, 0xf, 0xf, true));
-          const float a = up + XE[e];
+          // Dependent chain per step: sub_dpp, add, exp, add, log, add.  d is formed as (up - p) + (X - Y): the
+          // difference of the two lattice values first (exact or nearly so), the small terms after -- one op shorter
+          // than (up + X) - (p + Y) and without the rounding of two sums of magnitude |p|.  a, c and their max are
+          // off the chain.
+          const int pci = __builtin_bit_cast(int, pcur);
+          const float up1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pci, 0x138, 0xf, 0xf, true));
+          const float up2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pci, 0x138, 0xf, 0xf, true));
+          const float u = up1 - pcur;
+          const float d = u + DL[e];
+          const float a = up2 + XE[e];
           const float c = pcur + Y4[e];
-          const float d = a - c;
           const float mx = fmaxf(a, c);
           const float ex = __builtin_amdgcn_exp2f(-__builtin_fabsf(d));
           pcur = mx + __builtin_amdgcn_logf(1.0f + ex);
@@ -187,7 +195,9 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       const int kc = base + gg;
       if (kc >= 0 && kc < klast) {
         if (kc == 0) ecarry = in_ring[RINGN - 1];
+#ifndef FTR_EXP_NOCOMPUTE
         compute_chunk(kc);
+#endif
       }
       __syncthreads();
     }
@@ -207,7 +217,11 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       const int m = kc + LOOK;
       u64 g_next = 0;
       if (has_up && !dead && m + 1 >= 0 && m + 1 < klast_up) g_next = comm_peek(gran_in, m + 1, lane);
+#ifdef FTR_EXP_NOPOLL
+      if (false) {
+#else
       if (has_up && !dead && m >= 0 && m < klast_up) {
+#endif
         if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {   // producer never showed up: poison, stop polling
           dead = true;
           in_ring[lane] = __builtin_nanf("");
@@ -219,7 +233,10 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     return;
   }
 
-  // ========================================================================= IO wave
+  // ========================================================================= IO waves
+  // IO-in (wid 1): global loads three chunks ahead + parking the tiles.  IO-out (wid 3): turning the compute wave's
+  // per-cell output into G and storing it.  Measured (profiles/r01_h): with one IO wave doing both, its slot (1879
+  // ticks) and the compute wave's (2073) were balanced and neither could shrink alone.
   const int row0 = 64 * w;
   // staging geometry of this lane: in load/store instruction m it handles tile row 16m + (lane>>2), quad (lane&3)
   const int frow = lane >> 2, fq = lane & 3;
@@ -401,23 +418,36 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     }
   };
 
+  const int K0 = MOD ? 1 : 4;                                      // 16k - 63*SKEW >= 1
+  const int K1 = min((Tn >= CH) ? (Tn - CH) / CH + 1 : 0, klast);  // 16k + 15 < Tn
+
+  if (wid == 3) {
+    // ------------------------------------------------------------------------- IO-out
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int k = base + gg - 1;          // the chunk the compute wave finished in the previous slot
+      if (k >= 0 && k < klast) {
+        if (k >= K0 && k < K1) drain_fast(k);   // wave-uniform
+        else drain_general(k);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // --------------------------------------------------------------------------- IO-in
   auto slot_general = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
     if (kc + 1 >= 0 && kc + 1 < klast) park(kc + 1, x, y);
-    if (kc - 1 >= 0 && kc - 1 < klast) drain_general(kc - 1);
     if (kc + 1 + NPF >= 0 && kc + 1 + NPF < klast) load_general(kc + 1 + NPF, x, y);
     __syncthreads();
   };
   auto slot_fast = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
     park(kc + 1, x, y);         // loads of chunk kc+1 were issued NPF slots ago
-    drain_fast(kc - 1);
     load_fast(kc + 1 + NPF, x, y);
     __syncthreads();
   };
 
-  // Fast slot kc: the drained chunk kc-1 and the loaded chunk kc+1+NPF are interior and inside [0, klast).
-  const int K0 = MOD ? 1 : 4;                                      // 16k - 63*SKEW >= 1
-  const int K1 = min((Tn >= CH) ? (Tn - CH) / CH + 1 : 0, klast);  // 16k + 15 < Tn
-  const int KF0 = K0 + 1, KF1 = (Sn >= 2) ? K1 - 1 - NPF : 0;      // fast slots: KF0 <= kc < KF1
+  // Fast slot kc: the loaded chunk kc+1+NPF is interior and inside [0, klast), the parked chunk kc+1 exists.
+  const int KF0 = max(K0 - 1 - NPF, -1), KF1 = (Sn >= 2) ? K1 - 1 - NPF : 0;      // fast slots: KF0 <= kc < KF1
   int it1 = (KF0 - base + NPF - 1) / NPF;                // first iteration whose first slot has kc >= KF0
   int it2 = (KF1 - base) / NPF;                          // first iteration whose last slot has kc >= KF1
   it1 = min(max(it1, 0), NIT);
@@ -446,7 +476,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #undef FTR_TD
 
 template <bool MOD>
-__global__ __launch_bounds__(192) void mi_bidir_fwd_kernel(
+__global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
     const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
     float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, int B, int NB, int Tg, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -525,7 +555,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   constexpr int LOOK = MOD ? 1 : 5;
   constexpr int PRE = NPF + 1;
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO, 2 COMM
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
   const int T1 = MOD ? T : T + 1;
   const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
   const int NWact = (Sn + 63) >> 6;
@@ -557,7 +587,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     float inj = 0.0f;
     {
       const int r = 64 * w + lane;
-      if (r < Sn) inj = occ_b[REVM ? (Sn - 1 - r) : r] * ans_grad[b];
+      if (r < Sn) inj = occ_b[REVM ? (Sn - 1 - r) : r] * (ans_grad ? ans_grad[b] : 1.0f);   // NULL ans_grad = ones
     }
     float yprev = 0.0f, xprev = 0.0f, ecarry = 0.0f;
 
@@ -597,7 +627,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
         cPX[q * PLANE + lane] = PX4;
         cPY[q * PLANE + lane] = PY4;
         if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = XO4;
-        if (overwrite && (jfin >> 2) == (j0 >> 2)) {
+        if (overwrite && ans_grad && (jfin >> 2) == (j0 >> 2)) {
           const int e = jfin & 3;
           const float v = (e == 0) ? PG4[0] : (e == 1) ? PG4[1] : (e == 2) ? PG4[2] : PG4[3];
           if (lane == lfin) ans_grad[b] = v;
@@ -645,7 +675,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     return;
   }
 
-  // ========================================================================= IO wave
+  // ========================================================================= IO waves (IO-in = wid 1, IO-out = wid 3)
   const int row0 = 64 * w;
   const int frow = lane >> 2, fq = lane & 3;
   f4 rg[NPF][4];
@@ -794,23 +824,37 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     }
   };
 
+  const int K0 = max(MOD ? 1 : 4, kfirst);
+  const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;
+
+  if (wid == 3) {
+    // ------------------------------------------------------------------------- IO-out
+    const int K0d = max(MOD ? 1 : 4, kfirst + 1);     // the cut's chunk is drained with the per-step mask
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int k = base + gg - 1;
+      if (k >= kfirst && k < nchunks) {
+        if (k >= K0d && k < K1) drain_fast(k);   // wave-uniform
+        else drain_general(k);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // --------------------------------------------------------------------------- IO-in
   auto slot_general = [&](int kc, f4 (&gq)[4]) {
     if (kc + 1 >= kfirst && kc + 1 < nchunks) park(kc + 1, gq);
-    if (kc - 1 >= kfirst && kc - 1 < nchunks) drain_general(kc - 1);
     if (kc + 1 + NPF >= kfirst && kc + 1 + NPF < nchunks) load_general(kc + 1 + NPF, gq);
     __syncthreads();
   };
   auto slot_fast = [&](int kc, f4 (&gq)[4]) {
     park(kc + 1, gq);
-    drain_fast(kc - 1);
     load_fast(kc + 1 + NPF, gq);
     __syncthreads();
   };
 
-  // fast slot kc: drained chunk kc-1 interior and past the cut's chunk, loaded chunk kc+1+NPF interior
-  const int K0 = max(MOD ? 1 : 4, kfirst + 1);
-  const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;
-  const int KF0 = K0 + 1, KF1 = K1 - 1 - NPF;
+  // fast slot kc: loaded chunk kc+1+NPF interior (and not before the cut's chunk), parked chunk kc+1 exists
+  const int KF0 = max(K0 - 1 - NPF, kfirst - 1), KF1 = K1 - 1 - NPF;
   int it1 = (KF0 - base + NPF - 1) / NPF;
   int it2 = (KF1 - base) / NPF;
   it1 = min(max(it1, 0), NIT);
@@ -839,7 +883,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 #undef FTR_TPY
 
 template <bool MOD>
-__global__ __launch_bounds__(192) void mi_bidir_flow_kernel(
+__global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
     const int32_t* __restrict__ boundary, const float* __restrict__ ws, u64* __restrict__ gran,
     const float* __restrict__ occ, float* __restrict__ px_grad, float* __restrict__ py_grad,
     float* __restrict__ ans_grad, int overwrite, int B, int NB, int Tg, int S, int T) {
@@ -861,8 +905,8 @@ __global__ __launch_bounds__(192) void mi_bidir_flow_kernel(
   //      dir 0 workgroups fill px_grad, dir 1 workgroups fill py_grad.
   {
     const bool empty = (Sn <= 0 || Tn <= 0);
-    const int nwv = 3 * NB;                 // every band's three waves share the fill of this utterance
-    const int fwid = 3 * w + wid;
+    const int nwv = 4 * NB;                 // every band's four waves share the fill of this utterance
+    const int fwid = 4 * w + wid;
     if (dir == 0) {
       // px_grad is defined on rows [sb, se) x columns [tb, te - NOFF]
       const int xr0 = empty ? 0 : bd.sb, xr1 = empty ? 0 : bd.se;
@@ -937,8 +981,8 @@ int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, floa
   if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_fwd: memset failed"); return FTR_ERR_LAUNCH; }
   const size_t lds = bidir_lds_bytes();
   const dim3 grid(2 * B * l.NB);
-  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(192), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(192), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
   int rc = check_launch("mi_bidir_fwd");
   if (rc != FTR_OK) return rc;
   hipLaunchKernelGGL(mi_bidir_mid_kernel, dim3(B), dim3(256), 0, st, boundary, ws + l.pmid_off, ws + l.occ_off, ans, B, S, T);
@@ -953,8 +997,8 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float
   if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_bwd: memset failed"); return FTR_ERR_LAUNCH; }
   const size_t lds = bidir_lds_bytes();
   const dim3 grid(2 * B * l.NB);
-  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(192), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(192), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
 }
 

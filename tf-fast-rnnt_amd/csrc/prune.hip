@@ -356,16 +356,19 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_chunk_kernel(
   }
 }
 
+// items of the reduction list: bit 31 clear = row index into `partial`, bit 31 set = row index into g_lm_p
+constexpr int RED_CAP = 1024;
 __global__ __launch_bounds__(128) void do_pruning_bwd_reduce_kernel(
     const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, const float* __restrict__ partial,
     const int2* __restrict__ meta, float* __restrict__ d_lm, int T, int S1, int C, int r, int nbmax, int nchunks) {
   extern __shared__ int hits[];    // [nchunks] chunks that hold something for this row, ascending
-  __shared__ int nhits;
+  __shared__ unsigned items[RED_CAP];
+  __shared__ int sh_nhits, sh_nitems, sh_hi, sh_j0, sh_done;
   const int s = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   const int2* mb = meta + (size_t)b * nchunks;
   if (threadIdx.x < 64) {          // wave 0: 64 chunk descriptors per pass, ballot compaction keeps the order
-    const int lane = threadIdx.x;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     int cnt = 0;
     for (int c0 = 0; c0 < nchunks; c0 += 64) {
       const int ch = c0 + lane;
@@ -378,27 +381,68 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_reduce_kernel(
       if (hit) hits[cnt + __popcll(mask & lt)] = ch;
       cnt += __popcll(mask);
     }
-    if (lane == 0) nhits = cnt;
+    if (lane == 0) { sh_nhits = cnt; sh_hi = 0; sh_j0 = 0; sh_done = 0; }
   }
   __syncthreads();
-  const int n = nhits;
   const int n4 = C >> 2;
-  for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < n; ++i) {
-      const int ch = hits[i];
-      const int2 m = mb[ch];
-      if (m.y > 0) {
-        acc += reinterpret_cast<const f4u*>(partial + (((size_t)b * nchunks + ch) * nbmax + (s - m.x)) * C)[c4];
-      } else {
-        const int t0 = ch * TCH;
-        const int nrows = min(TCH, T - t0) * r;
-        const size_t row0 = ((size_t)b * T + t0) * r;
-        for (int j = 0; j < nrows; ++j)
-          if (ranges[row0 + j] == s) acc += reinterpret_cast<const f4u*>(g_lm_p + (row0 + j) * C)[c4];
+  for (int cb = 0; cb < n4; cb += 512) {   // 4 column quads per thread and sweep (one sweep for C <= 2048)
+    f4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+      if (threadIdx.x < 64) {
+        // wave 0 turns the next stretch of hits into row items, in (chunk, t, k) order: a chunk with bins gives one
+        // partial row; a chunk without (marked -1 by pass 1) is scanned here, 64 of its rows per ballot
+        int cnt = 0, hi = sh_hi, j0 = sh_j0;
+        const int nh = sh_nhits;
+        while (hi < nh && cnt <= RED_CAP - 64) {
+          const int ch = hits[hi];
+          const int2 m = mb[ch];
+          if (m.y > 0) {
+            if (lane == 0) items[cnt] = (unsigned)(((size_t)b * nchunks + ch) * nbmax + (s - m.x));
+            ++cnt; ++hi;
+          } else {
+            const int t0 = ch * TCH;
+            const int nrows = min(TCH, T - t0) * r;
+            const size_t row0 = ((size_t)b * T + t0) * r;
+            while (j0 < nrows && cnt <= RED_CAP - 64) {
+              const int j = j0 + lane;
+              const bool match = j < nrows && ranges[row0 + j] == s;
+              const unsigned long long mask = __ballot(match);
+              if (match) items[cnt + __popcll(mask & lt)] = 0x80000000u | (unsigned)(row0 + j);
+              cnt += __popcll(mask);
+              j0 += 64;
+            }
+            if (j0 >= nrows) { ++hi; j0 = 0; }
+          }
+        }
+        if (lane == 0) { sh_nitems = cnt; sh_hi = hi; sh_j0 = j0; sh_done = (hi >= nh); }
       }
+      __syncthreads();
+      const int n = sh_nitems;
+      const int done = sh_done;
+      for (int i = 0; i < n; ++i) {
+        const unsigned it = items[i];
+        const float* src = (it & 0x80000000u) ? g_lm_p + (size_t)(it & 0x7fffffffu) * C : partial + (size_t)it * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c4 = cb + threadIdx.x + 128 * q;
+          if (c4 < n4) acc[q] += reinterpret_cast<const f4u*>(src)[c4];
+        }
+      }
+      __syncthreads();
+      if (done) break;
     }
-    reinterpret_cast<f4u*>(d_lm + ((size_t)b * S1 + s) * C)[c4] = acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c4 = cb + threadIdx.x + 128 * q;
+      if (c4 < n4) reinterpret_cast<f4u*>(d_lm + ((size_t)b * S1 + s) * C)[c4] = acc[q];
+    }
+    if (cb + 512 < n4) {   // another column sweep: restart the item stream
+      __syncthreads();
+      if (threadIdx.x == 0) { sh_hi = 0; sh_j0 = 0; sh_done = 0; }
+      __syncthreads();
+    }
   }
 }
 

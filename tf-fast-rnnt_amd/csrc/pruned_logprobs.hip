@@ -129,7 +129,7 @@ template <bool MOD, bool VEC>
 __global__ void band_grad_kernel(const float* __restrict__ logits, const int32_t* __restrict__ symbols,
                                  const int32_t* __restrict__ ranges, const int32_t* __restrict__ boundary,
                                  const float* __restrict__ lse, const float* __restrict__ gpx,
-                                 const float* __restrict__ gpy, const float* __restrict__ scale, int blank,
+                                 const float* __restrict__ gpy, const Scale scale, int blank,
                                  float* __restrict__ glogits, size_t rows, int T, int S, int C, int r) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -143,7 +143,7 @@ __global__ void band_grad_kernel(const float* __restrict__ logits, const int32_t
   int s = s0 + k;                        // inverse of the roll: band slot k <-> lattice row (s0 + k) mod (S+1)
   if (s > S) s -= S + 1;
   const int te = boundary ? boundary[4 * b + 3] : T;
-  const float sc = scale ? scale[b] : 1.0f;
+  const float sc = scale.at(b);
   float gx = 0.0f;
   int sym = blank;
   if (s < S) {
@@ -182,7 +182,31 @@ __global__ void band_grad_kernel(const float* __restrict__ logits, const int32_t
   }
 }
 
+// loss tail (rnnt_loss.py:333,544-546,1124-1126,1487-1489): out = -ans (reduction 0), -mean (1) or -sum (2) over the
+// batch, one block, fixed summation tree (deterministic).
+__global__ __launch_bounds__(256) void negated_reduce_kernel(const float* __restrict__ ans, int B, int reduction,
+                                                             float* __restrict__ out) {
+  __shared__ float red[4];
+  if (reduction == 0) {
+    for (int b = threadIdx.x; b < B; b += 256) out[b] = -ans[b];
+    return;
+  }
+  float s = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 256) s += ans[b];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    out[0] = (reduction == 1) ? -(t / (float)B) : -t;
+  }
+}
 }  // namespace
+
+int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(negated_reduce_kernel, dim3(1), dim3(256), 0, st, ans, B, reduction, out);
+  return check_launch("negated_reduce");
+}
 
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges,
                         const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px,
@@ -209,7 +233,7 @@ int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32
 
 int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges,
                         const int32_t* boundary, int blank, const float* lse, const float* gpx,
-                        const float* gpy, const float* scale, float* glogits, int B, int T, int S, int C,
+                        const float* gpy, Scale scale, float* glogits, int B, int T, int S, int C,
                         int r, int modified, hipStream_t st) {
   const size_t rows = (size_t)B * T * r;
   if (rows == 0) return FTR_OK;

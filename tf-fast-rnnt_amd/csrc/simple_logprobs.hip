@@ -165,7 +165,7 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
 // one workgroup per (b, s) row: W[b,s,:] and the two row sums.  rsx[b,s] = sum_t gpx'[b,s,t] (0 for s == S),
 // rsy[b,s] = sum_t gpy[b,s,t]; gpx' = gpx with the overwritten cells (t == T, t == t_end) masked.
 template <bool MOD>
-__global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
+__global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy, const Scale scale,
                                     const float* __restrict__ prod, const int32_t* __restrict__ boundary,
                                     float* __restrict__ W, float* __restrict__ rsx, float* __restrict__ rsy,
                                     float cs, int T, int S) {
@@ -176,10 +176,11 @@ __global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* 
   const size_t rowy = ((size_t)b * (S + 1) + s) * T;
   const size_t rowx = ((size_t)b * S + s) * T1;
   float sx = 0.0f, sy = 0.0f;
+  const float sc = scale.at(b);
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
     float gx = 0.0f;
-    if (s < S && (MOD || t != te)) gx = gpx[rowx + t];
-    const float gy = gpy[rowy + t];
+    if (s < S && (MOD || t != te)) gx = gpx[rowx + t] * sc;
+    const float gy = gpy[rowy + t] * sc;
     sx += gx; sy += gy;
     W[rowy + t] = -cs * (gx + gy) / (prod[rowy + t] + kTiny);   // cs = 1 for the simple loss
   }
@@ -198,7 +199,7 @@ __global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* 
 // grid (ceil(T / TT), B); block 256 = 8 column-owner groups x 32 frames.  LDS: acc [TT][C + 1] + csy[8][TT].
 // Thread (ty, tx) owns the accumulator cells acc[tx][c] with c % 8 == ty: every cell has one owner.
 template <bool MOD>
-__global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
+__global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy, const Scale scale,
                                      const float* __restrict__ damp, const float* __restrict__ am_probs,
                                      const int32_t* __restrict__ symbols, const int32_t* __restrict__ boundary,
                                      int blank, float kdir, const float* __restrict__ uvec,
@@ -240,13 +241,14 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   }
   __syncthreads();
   float cs = 0.0f, cx = 0.0f;
+  const float sc = scale.at(b);
   if (xok) {
     const float* gcol = gpx + (size_t)b * S * T1 + t;
     int i = 0;
     for (; i + 3 < cnt; i += 4) {
       const int s_0 = slist[i], s_1 = slist[i + 1], s_2 = slist[i + 2], s_3 = slist[i + 3];
-      const float g0 = gcol[(size_t)s_0 * T1], g1 = gcol[(size_t)s_1 * T1];
-      const float g2 = gcol[(size_t)s_2 * T1], g3 = gcol[(size_t)s_3 * T1];
+      const float g0 = gcol[(size_t)s_0 * T1] * sc, g1 = gcol[(size_t)s_1 * T1] * sc;
+      const float g2 = gcol[(size_t)s_2 * T1] * sc, g3 = gcol[(size_t)s_3 * T1] * sc;
       acc[tx * ld + symb[s_0]] += g0; cx += g0;
       acc[tx * ld + symb[s_1]] += g1; cx += g1;
       acc[tx * ld + symb[s_2]] += g2; cx += g2;
@@ -254,14 +256,14 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
     }
     for (; i < cnt; ++i) {
       const int s_0 = slist[i];
-      const float g0 = gcol[(size_t)s_0 * T1];
+      const float g0 = gcol[(size_t)s_0 * T1] * sc;
       acc[tx * ld + symb[s_0]] += g0; cx += g0;
     }
   }
   if (tok) {
     const float* ycol = gpy + (size_t)b * (S + 1) * T + t;
 #pragma unroll 4
-    for (int s = ty; s <= S; s += 8) cs += ycol[(size_t)s * T];
+    for (int s = ty; s <= S; s += 8) cs += ycol[(size_t)s * T] * sc;
   }
   csy[ty * TT + tx] = cs;
   csx[ty * TT + tx] = cx;
@@ -375,15 +377,15 @@ int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols
   return check_launch("simple_logprobs_fwd");
 }
 
-int simple_logprobs_bwd_w(const float* gpx, const float* gpy, const float* prod, const int32_t* boundary,
+int simple_logprobs_bwd_w(const float* gpx, const float* gpy, Scale scale, const float* prod, const int32_t* boundary,
                           float* W, float* rsx, float* rsy, float cs, int B, int T, int S, int modified, hipStream_t st) {
   const dim3 grid(S + 1, B);
-  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, cs, T, S);
-  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, prod, boundary, W, rsx, rsy, cs, T, S);
+  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, scale, prod, boundary, W, rsx, rsy, cs, T, S);
+  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, scale, prod, boundary, W, rsx, rsy, cs, T, S);
   return check_launch("simple_logprobs_bwd_w");
 }
 
-int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp, const float* am_probs,
+int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* damp, const float* am_probs,
                            const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec,
                            const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C,
                            int modified, hipStream_t st) {
@@ -394,10 +396,10 @@ int simple_logprobs_bwd_am(const float* gpx, const float* gpy, const float* damp
   const dim3 grid((T + TT - 1) / TT, B);
   if (modified) {
     if ((rc = reserve_lds(simple_bwd_am_kernel<true>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_bwd_am_kernel<true>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
+    hipLaunchKernelGGL(simple_bwd_am_kernel<true>, grid, dim3(256), lds, st, gpx, gpy, scale, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
   } else {
     if ((rc = reserve_lds(simple_bwd_am_kernel<false>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_bwd_am_kernel<false>, grid, dim3(256), lds, st, gpx, gpy, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
+    hipLaunchKernelGGL(simple_bwd_am_kernel<false>, grid, dim3(256), lds, st, gpx, gpy, scale, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
   }
   return check_launch("simple_logprobs_bwd_am");
 }

@@ -12,7 +12,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libftr_hip.so")
+LIB_PATH = os.environ.get("FTR_LIB_PATH") or os.path.join(_HERE, "libftr_hip.so")   # override: diagnostic builds only
 _lib = None
 
 _c_fp = ctypes.c_void_p   # const float* (device)
@@ -38,6 +38,10 @@ _SIGNATURES = {
     "ftr_do_pruning_bwd_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_size_t, _c_st]),
     "ftr_pruned_logprobs_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_logprobs_bwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_negated_reduce_f32": (_i, [_c_fp, _i, _i, _c_fp, _c_st]),
+    "ftr_pruned_logprobs_bwd_scaled_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_simple_logprobs_bwd_w_scaled_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
+    "ftr_simple_logprobs_bwd_am_scaled_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_rowmax_exp_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
     "ftr_rowmax_exp_sum_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
     "ftr_smoothed_logprobs_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, _f, _f, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),

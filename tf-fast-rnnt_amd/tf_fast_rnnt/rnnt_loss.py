@@ -118,6 +118,85 @@ class _SimpleLogprobs(torch.autograd.Function):
         return d_lm, d_am, None, None, None, None, None
 
 
+class _SimpleLoss(torch.autograd.Function):
+    """rnnt_loss_simple for regular/modified as ONE graph node: builder kernels + GEMM, recursion forward + backward
+    (occupancies), native loss reduction; backward() feeds the occupancies with the upstream gradient folded in on
+    the fly (ftr_simple_logprobs_bwd_*_scaled_f32) -- no framework-side pass over a lattice anywhere."""
+
+    @staticmethod
+    def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, delay_penalty, code):
+        B, T, C = am.shape
+        S = lm.shape[1] - 1
+        T1 = T if modified else T + 1
+        amc = am.detach().contiguous(); lmc = lm.detach().contiguous()
+        dev = amc.device
+        am_probs = torch.empty_like(amc); lm_probs = torch.empty_like(lmc)
+        am_max = torch.empty((B, T), dtype=torch.float32, device=dev)
+        lm_max = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        px = torch.empty((B, S, T1), dtype=torch.float32, device=dev)
+        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(amc)
+            _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)        # :175-178
+            _lib.call("ftr_rowmax_exp_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
+            prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                         # :180-182
+            _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
+                      _ptr(lm_max), _ptr(boundary), int(termination_symbol), float(delay_penalty), _ptr(px), _ptr(py),
+                      B, T, S, C, int(modified), st)
+        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, True, ans_grad_is_one=True)
+        del px, py
+        loss = _negated_reduce_native(ans, code)
+        ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0),
+                              px_grad, py_grad)
+        ctx.has_boundary = boundary is not None
+        ctx.meta = (int(termination_symbol), int(modified), int(code))
+        ctx.mark_non_differentiable(px_grad, py_grad)
+        return loss, px_grad, py_grad
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):
+        am_probs, lm_probs, prod, symbols, boundary, px_grad, py_grad = ctx.saved_tensors
+        if not ctx.has_boundary:
+            boundary = None
+        blank, modified, code = ctx.meta
+        B, T, C = am_probs.shape
+        S = lm_probs.shape[1] - 1
+        dev = am_probs.device
+        scale, stride, mul = _upstream_scale(g_loss, code, B)
+        W = torch.empty_like(prod)
+        rsx = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        rsy = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        d_am = torch.empty_like(am_probs); d_lm = torch.empty_like(lm_probs)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(am_probs)
+            _lib.call("ftr_simple_logprobs_bwd_w_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
+                      _ptr(prod), _ptr(boundary), _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
+            dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+            damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
+            _lib.call("ftr_simple_logprobs_bwd_am_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
+                      _ptr(damp), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
+                      modified, st)
+            _lib.call("ftr_simple_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx), _ptr(rsy),
+                      blank, _ptr(d_lm), B, S, C, st)
+        return d_lm, d_am, None, None, None, None, None, None
+
+
+def _check_simple_inputs(lm, am, symbols, termination_symbol):
+    _require_gpu(am, "am"); _require_gpu(lm, "lm")
+    if am.dtype != torch.float32 or lm.dtype != torch.float32:
+        raise TypeError("am and lm must be float32")
+    B, T, C = am.shape
+    S = lm.shape[1] - 1
+    if lm.shape[0] != B or lm.shape[2] != C:
+        raise ValueError(f"lm {tuple(lm.shape)} and am {tuple(am.shape)} disagree")
+    symbols = torch.as_tensor(symbols, device=am.device)
+    if tuple(symbols.shape) != (B, S):
+        raise ValueError(f"symbols must have shape {(B, S)}, got {tuple(symbols.shape)}")
+    if not 0 <= int(termination_symbol) < C:
+        raise ValueError(f"termination_symbol {termination_symbol} not in [0, {C})")
+    return symbols.to(torch.int32).contiguous()
+
+
 def _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary, delay_penalty=0.0):
     _require_gpu(am, "am"); _require_gpu(lm, "lm")
     if am.dtype != torch.float32 or lm.dtype != torch.float32:
@@ -211,6 +290,30 @@ def _reduce(negated_loss: torch.Tensor, reduction: Optional[str]) -> torch.Tenso
     raise ValueError(f"reduction should be ('none' | 'mean' | 'sum'), given {reduction}")
 
 
+_REDUCTIONS = {"none": 0, "mean": 1, "sum": 2}
+
+
+def _reduction_code(reduction: Optional[str]) -> int:
+    if reduction not in _REDUCTIONS:
+        raise ValueError(f"reduction should be ('none' | 'mean' | 'sum'), given {reduction}")
+    return _REDUCTIONS[reduction]
+
+
+def _negated_reduce_native(ans: torch.Tensor, code: int) -> torch.Tensor:
+    """-ans / -mean / -sum in one native launch (the loss tail of rnnt_loss.py:333,544-546,1124-1126,1487-1489)."""
+    B = ans.shape[0]
+    out = torch.empty((B,) if code == 0 else (), dtype=torch.float32, device=ans.device)
+    with torch.cuda.device(ans.device):
+        _lib.call("ftr_negated_reduce_f32", _ptr(ans), B, code, _ptr(out), _stream_ptr(ans))
+    return out
+
+
+def _upstream_scale(g_loss: torch.Tensor, code: int, B: int):
+    """(pointer tensor, stride, multiplier) such that d loss / d ans[b] = scale[b * stride] * mul."""
+    g = g_loss.to(torch.float32).contiguous()
+    return g, (1 if code == 0 else 0), (-1.0 / B if code == 1 else -1.0)
+
+
 def _drive(px, py, boundary, reduction, calc_gradients):
     scores_and_grads = mutual_information_recursion(px=px, py=py, boundary=boundary, calc_gradients=calc_gradients)
     negated_loss = scores_and_grads[0] if calc_gradients else scores_and_grads
@@ -231,13 +334,17 @@ def rnnt_loss_simple(
 ) -> Union[torch.Tensor, Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]]:
     """rnnt_loss.py:225-338.  Returns loss, or (loss, (px_grad, py_grad)) when ``calc_gradients``."""
     _check_type(rnnt_type)
+    code = _reduction_code(reduction)
     boundary = _as_boundary(boundary, am.shape[0], am.device)
     if rnnt_type == "constrained":   # the penalty applies after px += py[:, 1:, :]  (:218-221, :305-321)
         px, py = _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary)
         px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
-    else:
-        px, py = _simple_logprobs_native(lm, am, symbols, termination_symbol, rnnt_type, boundary, delay_penalty)
-    return _drive(px, py, boundary, reduction, calc_gradients)
+        return _drive(px, py, boundary, reduction, calc_gradients)
+    symbols_i = _check_simple_inputs(lm, am, symbols, termination_symbol)
+    pen = float(delay_penalty) if delay_penalty > 0.0 else 0.0
+    loss, px_grad, py_grad = _SimpleLoss.apply(lm, am, symbols_i, termination_symbol, boundary, rnnt_type != "regular",
+                                               pen, code)
+    return (loss, (px_grad, py_grad)) if calc_gradients else loss
 
 
 def _identity_ranges(B: int, T: int, S1: int, device) -> torch.Tensor:
@@ -506,7 +613,7 @@ class _PrunedLoss(torch.autograd.Function):
     __init__.py:154-162, into the softmax-gradient writer)."""
 
     @staticmethod
-    def forward(ctx, logits, symbols, ranges, termination_symbol, boundary, modified, delay_penalty):
+    def forward(ctx, logits, symbols, ranges, termination_symbol, boundary, modified, delay_penalty, code):
         B, T, r, C = logits.shape
         S = symbols.shape[1]
         T1 = T if modified else T + 1
@@ -520,30 +627,30 @@ class _PrunedLoss(torch.autograd.Function):
                                                               int(termination_symbol), float(delay_penalty), _ptr(lse),
                                                               _ptr(px), _ptr(py), B, T, S, C, r, int(modified),
                                                               _stream_ptr(x))
-        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need)
+        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
         del px, py
         if need:
             ctx.save_for_backward(x, symbols, ranges, lse, px_grad, py_grad,
                                   boundary if boundary is not None else torch.empty(0))
         ctx.has_boundary = boundary is not None
-        ctx.meta = (int(termination_symbol), int(modified))
-        return ans
+        ctx.meta = (int(termination_symbol), int(modified), int(code))
+        return _negated_reduce_native(ans, code)
 
     @staticmethod
-    def backward(ctx, g_ans):
+    def backward(ctx, g_loss):
         x, symbols, ranges, lse, px_grad, py_grad, boundary = ctx.saved_tensors
         if not ctx.has_boundary:
             boundary = None
-        blank, modified = ctx.meta
+        blank, modified, code = ctx.meta
         B, T, r, C = x.shape
         S = symbols.shape[1]
         g = torch.empty_like(x)
-        scale = g_ans.to(torch.float32).contiguous()
+        scale, stride, mul = _upstream_scale(g_loss, code, B)
         with torch.cuda.device(x.device):
-            _lib.call("ftr_pruned_logprobs_bwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary), blank,
-                                                              _ptr(lse), _ptr(px_grad), _ptr(py_grad), _ptr(scale), _ptr(g),
-                                                              B, T, S, C, r, modified, _stream_ptr(x))
-        return g, None, None, None, None, None, None
+            _lib.call("ftr_pruned_logprobs_bwd_scaled_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary), blank,
+                      _ptr(lse), _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul, _ptr(g),
+                      B, T, S, C, r, modified, _stream_ptr(x))
+        return g, None, None, None, None, None, None, None
 
 
 def rnnt_loss_pruned(
@@ -560,18 +667,16 @@ def rnnt_loss_pruned(
     """rnnt_loss.py:1022-1130.  Returns the loss only (``calc_gradients`` is accepted and, as in the
     reference, only selects whether the op computes occupancies; here that follows ``requires_grad``)."""
     _check_type(rnnt_type)
-    if reduction not in ("none", "mean", "sum"):
-        raise ValueError(f"reduction should be ('none' | 'mean' | 'sum'), given {reduction}")
+    code = _reduction_code(reduction)
     symbols_i, ranges_i, boundary_i = _pruned_inputs(logits, symbols, ranges, boundary)
     if rnnt_type == "constrained":
         px, py = get_rnnt_logprobs_pruned(logits=logits, symbols=symbols_i, ranges=ranges_i,
                                           termination_symbol=termination_symbol, boundary=boundary_i, rnnt_type=rnnt_type)
         px = _apply_delay_penalty(px, boundary_i, rnnt_type, delay_penalty)
         negated_loss = mutual_information_recursion(px=px, py=py, boundary=boundary_i, calc_gradients=False)
-    else:
-        negated_loss = _PrunedLoss.apply(logits, symbols_i, ranges_i, termination_symbol, boundary_i,
-                                         rnnt_type != "regular", float(delay_penalty) if delay_penalty > 0.0 else 0.0)
-    return _reduce(negated_loss, reduction)
+        return _reduce(negated_loss, reduction)
+    return _PrunedLoss.apply(logits, symbols_i, ranges_i, termination_symbol, boundary_i, rnnt_type != "regular",
+                             float(delay_penalty) if delay_penalty > 0.0 else 0.0, code)
 
 
 class _SmoothedLogprobs(torch.autograd.Function):
