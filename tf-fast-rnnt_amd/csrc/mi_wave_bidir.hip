@@ -40,6 +40,22 @@ constexpr int NPFC = 3;          // chunks in flight in the IO wave's registers
 constexpr int kMaxSpin = 400000; // polls of ~1 us before a band gives up (never reached unless a producer died)
 typedef unsigned long long u64;
 
+// Diagnostic build (make STAMPS=1 [STAMP_BAND=n]): per-wave busy / barrier-wait ticks of the forward kernel's slots,
+// utterance 0, alpha direction, band FTR_STAMP_BAND; read back with ftr_debug_stamps():
+// g_stamps[4*wid + {0,1,2}] = {busy, wait, slots} for wid 0 compute, 1 IO-in, 2 COMM, 3 IO-out.
+#ifndef FTR_STAMP_BAND
+#define FTR_STAMP_BAND 0
+#endif
+#ifdef FTR_STAMPS
+#define FTR_SYNC_DECL unsigned long long st_last = 0, st_busy = 0, st_wait = 0, st_n = 0; FTR_STAMP(st_last)
+#define FTR_SYNC() do { unsigned long long a_, b_; FTR_STAMP(a_); __syncthreads(); FTR_STAMP(b_); st_busy += a_ - st_last; st_wait += b_ - a_; st_last = b_; ++st_n; } while (0)
+#define FTR_SYNC_REPORT(slot) do { if (!REVM && b == 0 && w == FTR_STAMP_BAND && lane == 0) { g_stamps[4 * (slot)] = st_busy; g_stamps[4 * (slot) + 1] = st_wait; g_stamps[4 * (slot) + 2] = st_n; } } while (0)
+#else
+#define FTR_SYNC_DECL do { } while (0)
+#define FTR_SYNC() __syncthreads()
+#define FTR_SYNC_REPORT(slot) do { } while (0)
+#endif
+
 __host__ __device__ inline int granules_per_band(int T, int modified) {
   const int nchunks = (T + 1 + (modified ? 0 : 63) + CH - 1) / CH;
   return CH * (nchunks + 1);
@@ -91,6 +107,7 @@ __device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
 #define FTR_TX(k) (lds + ((k) & 1) * TILE_F4)
 #define FTR_TY(k) (lds + (2 + ((k) & 1)) * TILE_F4)
 #define FTR_TD(k) (lds + (4 + ((k) & 1)) * TILE_F4)
+#define FTR_TP(k) (lds + (6 + ((k) & 1)) * TILE_F4)
 
 // ------------------------------------------------------------------------------------------------- forward
 // One direction of one band.  REVM selects the IO wave's addressing (see the header).
@@ -111,9 +128,8 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   const int NWact = (Sn + 63) >> 6;
 
   f4* lds = reinterpret_cast<f4*>(smem);
-  float* in_ring = reinterpret_cast<float*>(lds + 6 * TILE_F4);   // values of the band above (row row0-1)
-  float* out_ring = in_ring + RINGN;                              // this band's lane 63
-  for (int i = threadIdx.x; i < 2 * RINGN; i += blockDim.x) in_ring[i] = kNeg;
+  float* in_ring = reinterpret_cast<float*>(lds + 8 * TILE_F4);   // values of the band above (row row0-1)
+  for (int i = threadIdx.x; i < RINGN; i += blockDim.x) in_ring[i] = kNeg;
   __syncthreads();
 
   // Bands step in LOCAL walk steps (lane l of band w is on column j - SKEW * l at local step j): the cut, given in
@@ -132,19 +148,25 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   const int nslots = klast + PRE + 1;
   const int NIT = (nslots + NPF - 1) / NPF;
   const int base = -PRE;  // kc = base + gg
+  FTR_SYNC_DECL;
 
   if (wid == 0) {
     // ======================================================================= COMPUTE wave
     const f4* ring_in = reinterpret_cast<const f4*>(in_ring);
-    f4* ring_out = reinterpret_cast<f4*>(out_ring);
     float pcur = (w == 0 && lane == 0) ? 0.0f : kNeg;  // origin trick: p[origin] = 0 + (Y := 0)
     float ecarry = kNeg;
     const float lane0 = (lane == 0) ? 1.0f : 0.0f;
 
+    // A lone wave issues one VALU instruction per 4 cycles (16 for v_exp/v_log) whether or not it is on the dependent
+    // chain (scripts/micro/clockbench.hip: the bare chain costs 76 cycles per step at 2.4 GHz), so the step is kept
+    // to the arithmetic alone: both per-cell outputs -- copysign(e, d) for the IO-out wave and p itself for the COMM
+    // wave (hand-off to the band below, values on the cut) -- leave through LDS tiles with two unconditional
+    // ds_write_b128 per four steps; no exec masking, no selects, no global stores in this loop.
     auto compute_chunk = [&](int k) {
       const f4* cX = FTR_TX(k);
       const f4* cY = FTR_TY(k);
       f4* cD = FTR_TD(k);
+      f4* cP = FTR_TP(k);
       f4 Xn = cX[lane], Yn = cY[lane];
       f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
 #pragma unroll
@@ -159,35 +181,23 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
         f4 XE;
         XE[0] = __builtin_fmaf(lane0, ecarry, X4[0]); XE[1] = __builtin_fmaf(lane0, E4[0], X4[1]);
         XE[2] = __builtin_fmaf(lane0, E4[1], X4[2]);  XE[3] = __builtin_fmaf(lane0, E4[2], X4[3]);
-        const f4 DL = XE - Y4;   // off the chain: d = (up - p) + (X - Y)
+        const f4 DL = XE - Y4;   // d = (up - p) + (X - Y): the difference of the two lattice values first
         f4 V4, P4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          // Dependent chain per step: sub_dpp, add, exp, add, log, add.  d is formed as (up - p) + (X - Y): the
-          // difference of the two lattice values first (exact or nearly so), the small terms after -- one op shorter
-          // than (up + X) - (p + Y) and without the rounding of two sums of magnitude |p|.  a, c and their max are
-          // off the chain.
           const int pci = __builtin_bit_cast(int, pcur);
           const float up1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pci, 0x138, 0xf, 0xf, true));
           const float up2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, pci, 0x138, 0xf, 0xf, true));
-          const float u = up1 - pcur;
-          const float d = u + DL[e];
-          const float a = up2 + XE[e];
-          const float c = pcur + Y4[e];
-          const float mx = fmaxf(a, c);
+          const float d = (up1 - pcur) + DL[e];
+          const float mx = fmaxf(up2 + XE[e], pcur + Y4[e]);
           const float ex = __builtin_amdgcn_exp2f(-__builtin_fabsf(d));
           pcur = mx + __builtin_amdgcn_logf(1.0f + ex);
-          V4[e] = __builtin_copysignf(ex, d);  // exp2(-|d|) with the sign of d: all the IO wave needs for G
+          V4[e] = __builtin_copysignf(ex, d);  // exp2(-|d|) with the sign of d: all the IO-out wave needs for G
           P4[e] = pcur;
         }
         ecarry = E4[3];
         cD[q * PLANE + lane] = V4;
-        if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = P4;
-        if ((jl >> 2) == (j0 >> 2)) {  // wave-uniform: this band's values on the cut
-          const int e = jl & 3;
-          const float v = (e == 0) ? P4[0] : (e == 1) ? P4[1] : (e == 2) ? P4[2] : P4[3];
-          if (64 * w + lane < Sn) pmid_b[64 * w + lane] = v;
-        }
+        cP[q * PLANE + lane] = P4;
       }
     };
 
@@ -199,8 +209,9 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
         compute_chunk(kc);
 #endif
       }
-      __syncthreads();
+      FTR_SYNC();
     }
+    FTR_SYNC_REPORT(0);
     return;
   }
 
@@ -213,7 +224,17 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
-      if (has_down && kc - 1 >= 0 && kc - 1 < klast) comm_publish(out_ring, gran_out, kc - 1, lane);
+      if (kc - 1 >= 0 && kc - 1 < klast) {
+        const float* tp = reinterpret_cast<const float*>(FTR_TP(kc - 1));
+        if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk kc-1 -> granules of the band below
+          const int m = kc - 1;
+          const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
+          const u64 g = ((u64)(unsigned)(m + 1) << 32) | (u64)__float_as_uint(v);
+          __hip_atomic_store(gran_out + CH * m + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (kc - 1 == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
+          pmid_b[64 * w + lane] = tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)];
+      }
       const int m = kc + LOOK;
       u64 g_next = 0;
       if (has_up && !dead && m + 1 >= 0 && m + 1 < klast_up) g_next = comm_peek(gran_in, m + 1, lane);
@@ -228,8 +249,9 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
         }
       }
       g_cur = g_next;
-      __syncthreads();
+      FTR_SYNC();
     }
+    FTR_SYNC_REPORT(2);
     return;
   }
 
@@ -273,25 +295,27 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
             }
           }
         } else {
-          // element e is walk column c0+e, i.e. t = te - c0 - e: memory order is the reverse of e
+          // element e is walk column c0+e, i.e. t = te - c0 - e: memory order is the reverse of e.  The registers keep
+          // MEMORY order and park() swaps: reversing here would consume each load the moment it is issued (the
+          // compiler then waits vmcnt(0) after every load -- no prefetch at all; seen in the ISA of the first version)
           if (r >= 1) {  // px[s][t], s = se - r <= se - 1; modified: t <= te - 1
             const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * T1 + bd.te - c0 - 3;
             if (c0 >= NOFF && c0 + 3 < Tn) {
-              vx = rev4(*reinterpret_cast<const f4u*>(px + lo));
+              vx = *reinterpret_cast<const f4u*>(px + lo);      // memory order; park() reverses
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                if (c0 + e >= NOFF && c0 + e < Tn) vx[e] = px[lo + 3 - e];
+                if (c0 + e >= NOFF && c0 + e < Tn) vx[3 - e] = px[lo + 3 - e];
             }
           }
           {  // py[s][t], t <= te - 1
             const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * T + bd.te - c0 - 3;
             if (c0 >= 1 && c0 + 3 < Tn) {
-              vy = rev4(*reinterpret_cast<const f4u*>(py + lo));
+              vy = *reinterpret_cast<const f4u*>(py + lo);
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                if (c0 + e >= 1 && c0 + e < Tn) vy[e] = py[lo + 3 - e];
+                if (c0 + e >= 1 && c0 + e < Tn) vy[3 - e] = py[lo + 3 - e];
             }
           }
         }
@@ -311,8 +335,8 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       f4 xs, ys;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        xs[e] = fmaxf(x[m][e] * kLog2e, kNeg);  // log2 domain; -inf (and nan) -> kNeg
-        ys[e] = fmaxf(y[m][e] * kLog2e, kNeg);
+        xs[e] = fmaxf(x[m][REVM ? 3 - e : e] * kLog2e, kNeg);  // log2 domain; -inf (and nan) -> kNeg; REV: swap
+        ys[e] = fmaxf(y[m][REVM ? 3 - e : e] * kLog2e, kNeg);
       }
       if (m == 0 && kk == 0 && w == 0 && lane == 0) ys[0] = 0.0f;
       dX[fq * PLANE + row] = xs;
@@ -403,8 +427,8 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       const float* py_k = py - CH * k;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        x[m] = rev4(*reinterpret_cast<const f4u*>(px_k + offX[m]));
-        y[m] = rev4(*reinterpret_cast<const f4u*>(py_k + offY[m]));
+        x[m] = *reinterpret_cast<const f4u*>(px_k + offX[m]);   // memory order, see load_general
+        y[m] = *reinterpret_cast<const f4u*>(py_k + offY[m]);
       }
     }
   };
@@ -429,8 +453,9 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
         if (k >= K0 && k < K1) drain_fast(k);   // wave-uniform
         else drain_general(k);
       }
-      __syncthreads();
+      FTR_SYNC();
     }
+    FTR_SYNC_REPORT(3);
     return;
   }
 
@@ -438,12 +463,12 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   auto slot_general = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
     if (kc + 1 >= 0 && kc + 1 < klast) park(kc + 1, x, y);
     if (kc + 1 + NPF >= 0 && kc + 1 + NPF < klast) load_general(kc + 1 + NPF, x, y);
-    __syncthreads();
+    FTR_SYNC();
   };
   auto slot_fast = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
     park(kc + 1, x, y);         // loads of chunk kc+1 were issued NPF slots ago
     load_fast(kc + 1 + NPF, x, y);
-    __syncthreads();
+    FTR_SYNC();
   };
 
   // Fast slot kc: the loaded chunk kc+1+NPF is interior and inside [0, klast), the parked chunk kc+1 exists.
@@ -469,11 +494,13 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #pragma unroll
     for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
   }
+  FTR_SYNC_REPORT(1);
 }
 
 #undef FTR_TX
 #undef FTR_TY
 #undef FTR_TD
+#undef FTR_TP
 
 template <bool MOD>
 __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
@@ -692,11 +719,11 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           // element e is walk column c0+e, i.e. t = te - c0 - e; memory order is the reverse of e.
           const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
           if (c0 >= 0 && c0 + 3 < Tn) {
-            v = rev4(*reinterpret_cast<const f4u*>(wsb + lo));
+            v = *reinterpret_cast<const f4u*>(wsb + lo);          // memory order; park() reverses
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (c0 + e >= 0 && c0 + e < Tn) v[e] = wsb[lo + 3 - e];
+              if (c0 + e >= 0 && c0 + e < Tn) v[3 - e] = wsb[lo + 3 - e];
           }
         } else {
           const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
@@ -715,7 +742,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   auto park = [&](int kk, const f4 (&gq)[4]) {
     f4* dG = FTR_TG(kk);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) dG[fq * PLANE + 16 * m + frow] = gq[m];
+    for (int m = 0; m < 4; ++m) dG[fq * PLANE + 16 * m + frow] = REVM ? rev4(gq[m]) : gq[m];   // REV loads stay in memory order until here
   };
   // Steps up to and including the cut (local walk step <= jli) belong to the other half and are never written.
   auto drain_general = [&](int k) {
@@ -806,8 +833,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     const float* ws_k = REVM ? wsb - CH * k : wsb + CH * k;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const f4 t4 = *reinterpret_cast<const f4u*>(ws_k + offG[m]);
-      gq[m] = REVM ? rev4(t4) : t4;
+      gq[m] = *reinterpret_cast<const f4u*>(ws_k + offG[m]);
     }
   };
   auto drain_fast = [&](int k) {
@@ -946,7 +972,30 @@ __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
   else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, ans_grad, 0, b, w, Tg, S, T, cut.jm);
 }
 
-inline size_t bidir_lds_bytes() { return (size_t)6 * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }
+inline size_t bidir_lds_bytes() { return (size_t)8 * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }   // forward: 8 tiles + ring; flow: 6 tiles + 2 rings
+
+// The workgroup dispatcher fills a CU up to its resource limits before it moves on: with 26 KB of LDS per workgroup
+// it co-locates workgroups on a few CUs of each XCD while others idle, and the co-located compute waves (one chain
+// each, latency bound) share SIMDs with each other's IO waves -- the forward went 92 -> 139 us between 64 and 256
+// workgroups on a 256-CU chip (profiles/r01_h).  Asking for more LDS than a fair share caps the workgroups per CU at
+// ceil(total / CUs): one per CU while the grid fits the chip.
+inline size_t spread_lds(size_t need, int total_wgs) {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  int target = (total_wgs + ncu - 1) / ncu;
+  if (target < 1) target = 1;
+  const size_t cap = (size_t)160 * 1024 / (target + 1) + 1024;   // > 1/(target+1) of a CU's 160 KB
+  return need > cap ? need : cap;
+}
+template <typename K>
+inline int allow_big_lds(K kernel, const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_error("%s: cannot raise the dynamic LDS limit: %s", what, hipGetErrorString(e)); return FTR_ERR_LAUNCH; }
+  return FTR_OK;
+}
 
 struct BidirLayout {
   size_t lat;       // floats per ratio lattice (padded)
@@ -979,8 +1028,15 @@ int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, floa
   u64* gran = reinterpret_cast<u64*>(ws + l.gran_off);
   if ((reinterpret_cast<uintptr_t>(gran) & 7) != 0) { set_error("mi_bidir_fwd: workspace must be 16-byte aligned"); return FTR_ERR_INVALID_ARG; }
   if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_fwd: memset failed"); return FTR_ERR_LAUNCH; }
-  const size_t lds = bidir_lds_bytes();
   const dim3 grid(2 * B * l.NB);
+  const size_t lds = spread_lds(bidir_lds_bytes(), (int)grid.x);
+  static bool big_ok = false;
+  if (!big_ok) {
+    int rc = allow_big_lds(mi_bidir_fwd_kernel<true>, "mi_bidir_fwd");
+    if (rc == FTR_OK) rc = allow_big_lds(mi_bidir_fwd_kernel<false>, "mi_bidir_fwd");
+    if (rc != FTR_OK) return rc;
+    big_ok = true;
+  }
   if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
   else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
   int rc = check_launch("mi_bidir_fwd");
@@ -995,11 +1051,26 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float
   float* wsm = const_cast<float*>(ws);   // the granule tail of the workspace is scratch
   u64* gran = reinterpret_cast<u64*>(wsm + l.gran_off);
   if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_bwd: memset failed"); return FTR_ERR_LAUNCH; }
-  const size_t lds = bidir_lds_bytes();
   const dim3 grid(2 * B * l.NB);
+  const size_t lds = spread_lds(bidir_lds_bytes(), (int)grid.x);
+  static bool big_ok = false;
+  if (!big_ok) {
+    int rc = allow_big_lds(mi_bidir_flow_kernel<true>, "mi_bidir_bwd");
+    if (rc == FTR_OK) rc = allow_big_lds(mi_bidir_flow_kernel<false>, "mi_bidir_bwd");
+    if (rc != FTR_OK) return rc;
+    big_ok = true;
+  }
   if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
   else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
+}
+
+// diagnostic (make STAMPS=1): see FTR_SYNC above
+int debug_stamps(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) {
+    set_error("debug_stamps: hipMemcpyFromSymbol failed"); return FTR_ERR_LAUNCH;
+  }
+  return FTR_OK;
 }
 
 }  // namespace ftr

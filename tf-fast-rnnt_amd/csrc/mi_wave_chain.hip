@@ -773,12 +773,4 @@ int mi_chain_bwd(const int32_t* boundary, const float* ws, float* px_grad, float
   return check_launch("mi_chain_bwd");
 }
 
-// diagnostic (make STAMPS=1): s_memtime sums of the chain kernels' steady-state slots, band 0 of utterance 0
-int debug_stamps(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) {
-    set_error("debug_stamps: hipMemcpyFromSymbol failed"); return FTR_ERR_LAUNCH;
-  }
-  return FTR_OK;
-}
-
 }  // namespace ftr
