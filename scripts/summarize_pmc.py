@@ -2,11 +2,12 @@
 `bench.py` into per-kernel HBM traffic per launch.  gfx950 corrections (MI355X_MICROARCH.md, HBM section): both
 counters are in KiB; FETCH_SIZE reports exactly half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
 exact for 16-byte-per-lane streaming stores.  Usage: summarize_pmc.py <fetch_dir> <write_dir> <out.json>"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 def load(d, counter):
     out = collections.defaultdict(list)
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:          # the newest pass only (gpurun merges every call's output into the same directory)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 out[r["Kernel_Name"]].append(float(r["Counter_Value"]))

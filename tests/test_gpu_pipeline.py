@@ -364,3 +364,45 @@ def test_do_pruning_backward_chunked(ft, dev, kind, same_tensor):
     want = torch.zeros((B, S1, C), dtype=torch.float64, device=dev)
     want.index_put_((torch.arange(B, device=dev).view(B, 1, 1).expand(B, T, r), ranges.long()), w2.double(), accumulate=True)
     np.testing.assert_allclose(lm.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("reduction", ["none", "mean", "sum"])
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
+def test_fused_loss_nodes_match_composed_path(ft, dev, reduction, rnnt_type):
+    """rnnt_loss_simple / rnnt_loss_pruned as single autograd nodes (native reduction, upstream gradient folded into the
+    backward kernels: ftr_negated_reduce_f32, ftr_*_scaled_f32) against the same losses composed from the public
+    pieces (px/py builder -> mutual_information_recursion -> torch reduction), values and gradients, with a non-trivial
+    upstream gradient.  Same kernels underneath: 1e-5."""
+    d = synthetic(41, 3, 30, 9, 12, ragged=True)
+    sym = _t(d["symbols"], dev); bd = _t(d["boundary"], dev); blank = d["termination_symbol"]
+    g = torch.Generator(device="cpu").manual_seed(9)
+    wgt = torch.rand((3,), generator=g).to(dev) + 0.5
+
+    def run(fused):
+        am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+        if fused:
+            loss, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, rnnt_type, 0.15, reduction, True)
+        else:
+            px, py = ft.get_rnnt_logprobs(lm, am, sym, blank, rnnt_type, bd)
+            from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty, _reduce
+            px = _apply_delay_penalty(px, bd, rnnt_type, 0.15)
+            ans, (gx, gy) = ft.mutual_information_recursion(px, py, bd, True)
+            loss = _reduce(ans, reduction)
+        ranges = ft.get_rnnt_prune_ranges(gx, gy, bd, 4)
+        am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
+        logits = torch.tanh(am_p + lm_p)
+        if fused:
+            ploss = ft.rnnt_loss_pruned(logits, sym, ranges, blank, bd, rnnt_type, 0.1, reduction)
+        else:
+            from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty, _reduce
+            ppx, ppy = ft.get_rnnt_logprobs_pruned(logits, sym, ranges, blank, bd, rnnt_type)
+            ppx = _apply_delay_penalty(ppx, bd, rnnt_type, 0.1)
+            ploss = _reduce(ft.mutual_information_recursion(ppx, ppy, bd), reduction)
+        total = (loss * wgt).sum() + 0.7 * (ploss * wgt).sum() if reduction == "none" else 1.3 * loss + 0.7 * ploss
+        total.backward()
+        return loss.detach().cpu().numpy(), ploss.detach().cpu().numpy(), am.grad.cpu().numpy(), lm.grad.cpu().numpy()
+
+    a = run(True); b = run(False)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5)
+    assert max_rel(a[2], b[2]) <= 1e-5 and max_rel(a[3], b[3]) <= 1e-5
