@@ -130,24 +130,42 @@ __global__ void prune_adjust_kernel(int32_t* __restrict__ s_begin, int32_t* __re
 
 // one thread per 16 bytes of output row (vector path, C % 4 == 0) or per element (scalar path)
 template <bool VEC>
-__global__ void do_pruning_kernel(const float* __restrict__ am, const float* __restrict__ lm,
-                                  const int32_t* __restrict__ ranges, float* __restrict__ am_p,
-                                  float* __restrict__ lm_p, int T, int S1, int C, int r, size_t total) {
-  const int per_row = VEC ? (C >> 2) : C;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t row = i / per_row;           // (b*T + t)*r + k
-    const int c = (int)(i - row * per_row);
-    const size_t bt = row / r;                // b*T + t
-    const size_t b = bt / T;
-    const int s = ranges[row];
-    if (VEC) {
-      const f4 a = reinterpret_cast<const f4u*>(am + bt * C)[c];
-      const f4 l = reinterpret_cast<const f4u*>(lm + (b * S1 + s) * C)[c];
-      reinterpret_cast<f4u*>(am_p + row * C)[c] = a;
-      reinterpret_cast<f4u*>(lm_p + row * C)[c] = l;
-    } else {
-      am_p[row * C + c] = am[bt * C + c];
-      lm_p[row * C + c] = lm[(b * S1 + s) * C + c];
+__global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict__ am, const float* __restrict__ lm,
+                                                         const int32_t* __restrict__ ranges, float* __restrict__ am_p,
+                                                         float* __restrict__ lm_p, int T, int S1, int C, int r) {
+  // one block per frame (b,t): the am row is read once and written r times, the r lm rows are gathered; the outputs
+  // (2 * N bytes, far beyond any cache) are written with non-temporal stores.  No per-thread index divisions.
+  const size_t bt = blockIdx.x;
+  const size_t b = bt / T;
+  const int32_t* rg = ranges + bt * r;
+  const float* lmb = lm + b * S1 * C;
+  float* ao = am_p + bt * r * C;
+  float* lo = lm_p + bt * r * C;
+  if (VEC) {
+    const int n4 = C >> 2;
+    const f4u* arow = reinterpret_cast<const f4u*>(am + bt * C);
+    for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
+      const f4 a = arow[c4];
+      for (int k0 = 0; k0 < r; k0 += 8) {
+        f4 l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < r) l[u] = reinterpret_cast<const f4u*>(lmb + (size_t)rg[k0 + u] * C)[c4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < r) {
+            __builtin_nontemporal_store(a, reinterpret_cast<f4u*>(ao + (size_t)(k0 + u) * C) + c4);
+            __builtin_nontemporal_store(l[u], reinterpret_cast<f4u*>(lo + (size_t)(k0 + u) * C) + c4);
+          }
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 128) {
+      const float a = am[bt * C + c];
+      for (int k = 0; k < r; ++k) {
+        ao[(size_t)k * C + c] = a;
+        lo[(size_t)k * C + c] = lmb[(size_t)rg[k] * C + c];
+      }
     }
   }
 }
@@ -282,8 +300,8 @@ __global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const
 // columns: no atomics, no barriers, fixed order).  When the two incoming gradients are the same tensor (the joiner
 // starts with am_pruned + lm_pruned, so autograd hands the same buffer to both) the sum over k that gives d am is
 // taken from the same registers (FUSE).  The bins go to `partial` [B][nchunks][nbmax][C]; meta = {smin, nb}.
-// A chunk whose rows span more than nbmax lattice rows (never for get_rnnt_prune_ranges output at sane sizes, but
-// `ranges` is caller data) is marked nb = -1 and left to pass 2.
+// A chunk whose rows span more than nbmax lattice rows (a burst of the staircase, or arbitrary caller data) is marked
+// nb = -(span) and left to pass 2, which rescans it for the rows inside its span only.
 // Pass 2, one block per (b,s): adds the (at most a few) partial rows that cover s in chunk order; for chunks marked
 // -1 it scans the chunk's ranges and adds the matching rows of g directly.
 constexpr int TCH = 16;
@@ -316,7 +334,8 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_chunk_kernel(
   const int smin = min(red[0], red[2]), smax = max(red[1], red[3]);
   const int nb = smax - smin + 1;
   const bool ok = smin >= 0 && nb <= nbmax;
-  if (threadIdx.x == 0) meta[(size_t)b * nchunks + chunk] = ok ? make_int2(smin, nb) : make_int2(0, -1);
+  // a chunk without bins still records which lattice rows it touches (nb < 0): pass 2 rescans it only for those
+  if (threadIdx.x == 0) meta[(size_t)b * nchunks + chunk] = ok ? make_int2(smin, nb) : make_int2(min(smin, smax), (smin >= 0 && smax >= smin) ? -(smax - smin + 1) : -0x40000000);
   if (!ok && !FUSE) return;
   const int n4 = C >> 2;
   const size_t row0 = ((size_t)b * T + t0) * r;
@@ -375,7 +394,8 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_reduce_kernel(
       bool hit = false;
       if (ch < nchunks) {
         const int2 m = mb[ch];
-        hit = (m.y < 0) || (m.y > 0 && s >= m.x && s < m.x + m.y);
+        const int span = m.y < 0 ? -m.y : m.y;
+        hit = m.y != 0 && (m.y == -0x40000000 || (s >= m.x && s - m.x < span));
       }
       const unsigned long long mask = __ballot(hit);
       if (hit) hits[cnt + __popcll(mask & lt)] = ch;
@@ -500,22 +520,13 @@ int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boun
   return check_launch("prune_adjust");
 }
 
-int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B,
-               int T, int S1, int C, int r, hipStream_t st) {
-  const size_t rows = (size_t)B * T * r;
-  if (rows == 0 || C == 0) return FTR_OK;
-  const int threads = 256;
-  if ((C & 3) == 0) {
-    const size_t total = rows * (size_t)(C >> 2);
-    const size_t blocks = (total + threads - 1) / threads;
-    hipLaunchKernelGGL(do_pruning_kernel<true>, dim3((unsigned)(blocks > 0x7fffffffull ? 0x7fffffffull : blocks)), dim3(threads), 0, st,
-                       am, lm, ranges, am_p, lm_p, T, S1, C, r, total);
-  } else {
-    const size_t total = rows * (size_t)C;
-    const size_t blocks = (total + threads - 1) / threads;
-    hipLaunchKernelGGL(do_pruning_kernel<false>, dim3((unsigned)(blocks > 0x7fffffffull ? 0x7fffffffull : blocks)), dim3(threads), 0, st,
-                       am, lm, ranges, am_p, lm_p, T, S1, C, r, total);
-  }
+int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1,
+               int C, int r, hipStream_t st) {
+  const size_t frames = (size_t)B * T;
+  if (frames == 0 || C == 0 || r == 0) return FTR_OK;
+  if (frames > 0x7fffffffull) { set_error("do_pruning: B*T = %zu exceeds the grid limit", frames); return FTR_ERR_UNSUPPORTED; }
+  if ((C & 3) == 0) hipLaunchKernelGGL(do_pruning_kernel<true>, dim3((unsigned)frames), dim3(128), 0, st, am, lm, ranges, am_p, lm_p, T, S1, C, r);
+  else hipLaunchKernelGGL(do_pruning_kernel<false>, dim3((unsigned)frames), dim3(128), 0, st, am, lm, ranges, am_p, lm_p, T, S1, C, r);
   return check_launch("do_pruning");
 }
 

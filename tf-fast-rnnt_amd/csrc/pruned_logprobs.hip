@@ -12,50 +12,68 @@ namespace ftr {
 namespace {
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64));  v = fmaxf(v, __shfl_xor(v, 2, 64));  v = fmaxf(v, __shfl_xor(v, 1, 64));
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);  v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 1, 64);
   return v;
 }
 
 // logsumexp of each row, the row held in registers (C % 4 == 0, C <= 256 * NQ): one 16-byte load per lane and quad,
 // all of a wave's loads (RW rows x NQ quads) issued before the first is used, a single pass over the data.
 template <int NQ, int RW>
-__global__ void lse_rows_reg_kernel(const float* __restrict__ logits, float* __restrict__ lse, size_t rows, int C) {
+__global__ __launch_bounds__(256) void lse_rows_reg_kernel(const float* __restrict__ logits, float* __restrict__ lse,
+                                                           size_t rows, int C) {
+  // persistent waves: RW rows per pass, the next pass's rows are requested before this pass is reduced
   const int lane = threadIdx.x & 63;
-  const size_t row0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RW;
-  if (row0 >= rows) return;
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const int n4 = C >> 2;
-  f4 v[RW][NQ];
+  const f4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  auto fetch = [&](size_t row0, f4 (&v)[RW][NQ]) {
 #pragma unroll
-  for (int w = 0; w < RW; ++w) {
-    const size_t row = (row0 + w < rows) ? row0 + w : rows - 1;   // tail: recompute the last row, write guarded below
-    const f4u* x4 = reinterpret_cast<const f4u*>(logits + row * C);
+    for (int w = 0; w < RW; ++w) {
+      const size_t row = (row0 + w < rows) ? row0 + w : rows - 1;   // tail: recompute the last row, write guarded below
+      const f4u* x4 = reinterpret_cast<const f4u*>(logits + row * C);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int i = lane + 64 * q;
-      const f4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      v[w][q] = (i < n4) ? (f4)x4[i] : ninf;
+      for (int q = 0; q < NQ; ++q) {
+        const int i = lane + 64 * q;
+        v[w][q] = (i < n4) ? (f4)x4[i] : ninf;
+      }
     }
-  }
+  };
+  size_t row0 = wave * RW;
+  if (row0 >= rows) return;
+  f4 cur[RW][NQ], nxt[RW][NQ];
+  fetch(row0, cur);
+  for (;;) {
+    const size_t rown = row0 + nwaves * RW;
+    const bool more = rown < rows;
+    if (more) fetch(rown, nxt);
 #pragma unroll
-  for (int w = 0; w < RW; ++w) {
-    float m = -INFINITY;
+    for (int w = 0; w < RW; ++w) {
+      float m = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(v[w][q][0], v[w][q][1])), fmaxf(v[w][q][2], v[w][q][3]));
-    m = wave_max(m);
-    float sum = 0.0f;
+      for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(cur[w][q][0], cur[w][q][1])), fmaxf(cur[w][q][2], cur[w][q][3]));
+      m = wave_max(m);
+      float sum = 0.0f;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel: bit-identical lse
-        sum += __expf(v[w][q][0] - m) + __expf(v[w][q][1] - m) + __expf(v[w][q][2] - m) + __expf(v[w][q][3] - m);
+      for (int q = 0; q < NQ; ++q) {
+        if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel: bit-identical lse
+          sum += __expf(cur[w][q][0] - m) + __expf(cur[w][q][1] - m) + __expf(cur[w][q][2] - m) + __expf(cur[w][q][3] - m);
+      }
+      sum = wave_sum(sum);
+      if (lane == 0 && row0 + w < rows) lse[row0 + w] = m + __logf(sum);
     }
-    sum = wave_sum(sum);
-    if (lane == 0 && row0 + w < rows) lse[row0 + w] = m + __logf(sum);
+    if (!more) break;
+#pragma unroll
+    for (int w = 0; w < RW; ++w)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) cur[w][q] = nxt[w][q];
+    row0 = rown;
   }
 }
 
@@ -216,7 +234,8 @@ int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
   constexpr int RW = 2;
-  const unsigned blocks_reg = (unsigned)((rows + (size_t)wpb * RW - 1) / ((size_t)wpb * RW));
+  const size_t want = (rows + (size_t)wpb * RW - 1) / ((size_t)wpb * RW);
+  const unsigned blocks_reg = (unsigned)(want < 2048 ? want : 2048);   // 8 blocks of 4 waves per CU, grid-stride
   if ((C & 3) == 0 && C <= 256) hipLaunchKernelGGL((lse_rows_reg_kernel<1, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else if ((C & 3) == 0 && C <= 512) hipLaunchKernelGGL((lse_rows_reg_kernel<2, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else if ((C & 3) == 0 && C <= 1024) hipLaunchKernelGGL((lse_rows_reg_kernel<4, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
