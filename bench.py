@@ -242,6 +242,36 @@ def cpu_baseline(B, T, S, C, r, sample_B=8, seed=0, min_seconds=12.0):
                        f"px/py and pruned logits, without the autograd tail to am/lm)")
 
 
+# ------------------------------------------------------------------------------------------------ hipGraph replay
+def graph_replay(step_fn, steps):
+    """The same step captured once into a hipGraph (torch.cuda.CUDAGraph: every native call, memset node and library
+    GEMM of the step lands in the graph -- the package never synchronises with the host) and replayed `steps` times.
+    Reported next to the eager number; `value` stays the eager one (per-call HIP events cannot live inside a graph)."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step_fn()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dict(ms_per_step=round(1e3 * dt / steps, 4), loss=float(out.item()))
+    except Exception as e:   # capture not possible in this environment: report why, do not fail the bench line
+        return dict(ms_per_step=None, error=f"{type(e).__name__}: {e}"[:300])
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -251,6 +281,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
     ap.add_argument("--first-pass", default=None, choices=["simple", "smoothed"],
                     help="occupancy pass; default simple, smoothed for c4 (BASELINE.json configs[3])")
     args = ap.parse_args()
@@ -372,6 +403,11 @@ def main():
         "kernels": kernels,
         "loss": float(last.item()),
     }
+    if world == 1 and not args.no_graph:
+        gr = graph_replay(lambda: pruned_step(inp, r, first_pass=first_pass), args.steps)
+        if gr.get("ms_per_step"):
+            gr["value"] = round(B / (gr["ms_per_step"] * 1e-3), 2)
+        out["graph_replay"] = gr
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(B, T, S, C, r)
     else:

@@ -7,7 +7,7 @@ if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 python - <<'PY'
 import json
 d = json.load(open('gpurun_out/bench.json'))
-print("ms/step", d["ms_per_step"], "value", d["value"], "native_us", d["native_us_per_step"], "peak MB", d["peak_mem_mb"], "roofline", d["roofline"])
+print("graph", d.get("graph_replay")); print("ms/step", d["ms_per_step"], "value", d["value"], "native_us", d["native_us_per_step"], "peak MB", d["peak_mem_mb"], "roofline", d["roofline"])
 for k,v in d["kernels"].items(): print(f"  {k:40s} {v['avg_us']:8.1f} us x{v['calls_per_step']}  {v['GBps']} GB/s")
 PY
 timeout -k 10 300 python bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; rc=$?; echo "bench c4 exit $rc"
@@ -23,7 +23,7 @@ PY
 if [ -z "$FTR_PROFILE" ]; then exit 0; fi
 rm -rf gpurun_out/prof_r1 gpurun_out/pmc_fetch gpurun_out/pmc_write
 R=$PWD; cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "prof exit $?" >> $R/gpurun_out/prof.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "prof exit $?" >> $R/gpurun_out/prof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
 cd $R; tail -2 gpurun_out/prof.err; ls gpurun_out/pmc_fetch/*/ | head -3

@@ -61,29 +61,41 @@ __global__ void prune_argmax_kernel(const float* __restrict__ px_grad, const flo
   float bestv = 0.0f;
   // The cumulative sums must be taken in this order (bit-exact ranges), but the loads do not depend on them: fetch
   // CHK windows' worth of operands first (3 * CHK independent loads in flight), then run the serial arithmetic.
-  constexpr int CHK = 32;
-  for (int c0 = 0; c0 < nwin; c0 += CHK) {
-    float ld[CHK], lg[CHK], xv[CHK];
+  constexpr int CHK = 16;
+  float ld[2][CHK], lg[2][CHK], xv[2][CHK];
+  auto fetch = [&](int c0, float (&l)[CHK], float (&g)[CHK], float (&x)[CHK]) {
 #pragma unroll
     for (int u = 0; u < CHK; ++u) {
       const int s0 = c0 + u;
       const bool more = s0 + 1 < nwin;
-      ld[u] = more ? pyc[(size_t)(s0 + r) * T] : 0.0f;
-      lg[u] = more ? pyc[(size_t)s0 * T] : 0.0f;
-      xv[u] = (s0 > 0 && s0 < nwin) ? pxc[(size_t)(s0 - 1) * T1] : 0.0f;
+      l[u] = more ? pyc[(size_t)(s0 + r) * T] : 0.0f;
+      g[u] = more ? pyc[(size_t)s0 * T] : 0.0f;
+      x[u] = (s0 > 0 && s0 < nwin) ? pxc[(size_t)(s0 - 1) * T1] : 0.0f;
     }
+  };
+  auto consume = [&](int c0, const float (&l)[CHK], const float (&g)[CHK], const float (&x)[CHK]) {
 #pragma unroll
     for (int u = 0; u < CHK; ++u) {
       const int s0 = c0 + u;
       if (s0 < nwin) {
         const float blk = lead - lag;                                      // rnnt_loss.py:725
-        const float fin = blk - xv[u];                                     // :726-728 (px_pad[.,0] = 0)
+        const float fin = blk - x[u];                                      // :726-728 (px_pad[.,0] = 0)
         if (s0 == 0 || fin > bestv) { best = s0; bestv = fin; }            // :729, first maximum
         if (s0 + 1 < nwin) {
-          lead = lead + ld[u];
-          lag = lag + lg[u];
+          lead = lead + l[u];
+          lag = lag + g[u];
         }
       }
+    }
+  };
+  // two chunks in flight: the next chunk's 3 * CHK loads are issued before the current chunk's serial adds run
+  fetch(0, ld[0], lg[0], xv[0]);
+  for (int c0 = 0; c0 < nwin; c0 += 2 * CHK) {
+    if (c0 + CHK < nwin) fetch(c0 + CHK, ld[1], lg[1], xv[1]);
+    consume(c0, ld[0], lg[0], xv[0]);
+    if (c0 + CHK < nwin) {
+      if (c0 + 2 * CHK < nwin) fetch(c0 + 2 * CHK, ld[0], lg[0], xv[0]);
+      consume(c0 + CHK, ld[1], lg[1], xv[1]);
     }
   }
   const int se = boundary[4 * b + 2], te = boundary[4 * b + 3];
