@@ -388,92 +388,108 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_chunk_kernel(
 }
 
 // items of the reduction list: bit 31 clear = row index into `partial`, bit 31 set = row index into g_lm_p
-constexpr int RED_CAP = 1024;
-__global__ __launch_bounds__(128) void do_pruning_bwd_reduce_kernel(
+constexpr int RED_CAP = 512;
+// One WAVE per (b,s) (no barriers: a wave is in lock step): it lists the chunks that hold something for its row with
+// ballots, expands them into row items in (chunk, t, k) order -- a chunk with bins gives one partial row, a chunk
+// without is scanned here, 128 of its rows per pass -- and adds the rows, four loads in flight.
+__global__ __launch_bounds__(64) void do_pruning_bwd_reduce_kernel(
     const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, const float* __restrict__ partial,
     const int2* __restrict__ meta, float* __restrict__ d_lm, int T, int S1, int C, int r, int nbmax, int nchunks) {
-  extern __shared__ int hits[];    // [nchunks] chunks that hold something for this row, ascending
+  extern __shared__ int hits[];    // [3 * nchunks]: chunk id, first row (or first lattice row), span (< 0: no bins)
   __shared__ unsigned items[RED_CAP];
-  __shared__ int sh_nhits, sh_nitems, sh_hi, sh_j0, sh_done;
   const int s = blockIdx.x, b = blockIdx.y;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const int2* mb = meta + (size_t)b * nchunks;
-  if (threadIdx.x < 64) {          // wave 0: 64 chunk descriptors per pass, ballot compaction keeps the order
-    int cnt = 0;
-    for (int c0 = 0; c0 < nchunks; c0 += 64) {
-      const int ch = c0 + lane;
-      bool hit = false;
-      if (ch < nchunks) {
-        const int2 m = mb[ch];
-        const int span = m.y < 0 ? -m.y : m.y;
-        hit = m.y != 0 && (m.y == -0x40000000 || (s >= m.x && s - m.x < span));
-      }
-      const unsigned long long mask = __ballot(hit);
-      if (hit) hits[cnt + __popcll(mask & lt)] = ch;
-      cnt += __popcll(mask);
+  int nh = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    const int ch = c0 + lane;
+    bool hit = false;
+    int2 m = make_int2(0, 0);
+    if (ch < nchunks) {
+      m = mb[ch];
+      const int span = m.y < 0 ? -m.y : m.y;
+      hit = m.y != 0 && (m.y == -0x40000000 || (s >= m.x && s - m.x < span));
     }
-    if (lane == 0) { sh_nhits = cnt; sh_hi = 0; sh_j0 = 0; sh_done = 0; }
+    const unsigned long long mask = __ballot(hit);
+    if (hit) {
+      const int pos = nh + __popcll(mask & lt);
+      hits[3 * pos] = ch; hits[3 * pos + 1] = m.x; hits[3 * pos + 2] = m.y;
+    }
+    nh += __popcll(mask);
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wave: LDS accesses execute in program order,
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the fences only keep the compiler from reordering them
   const int n4 = C >> 2;
-  for (int cb = 0; cb < n4; cb += 512) {   // 4 column quads per thread and sweep (one sweep for C <= 2048)
+  float* out = d_lm + ((size_t)b * S1 + s) * C;
+  for (int cb = 0; cb < n4; cb += 256) {   // 4 column quads per lane and sweep (one sweep for C <= 1024)
     f4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
-    for (;;) {
-      if (threadIdx.x < 64) {
-        // wave 0 turns the next stretch of hits into row items, in (chunk, t, k) order: a chunk with bins gives one
-        // partial row; a chunk without (marked -1 by pass 1) is scanned here, 64 of its rows per ballot
-        int cnt = 0, hi = sh_hi, j0 = sh_j0;
-        const int nh = sh_nhits;
-        while (hi < nh && cnt <= RED_CAP - 64) {
-          const int ch = hits[hi];
-          const int2 m = mb[ch];
-          if (m.y > 0) {
-            if (lane == 0) items[cnt] = (unsigned)(((size_t)b * nchunks + ch) * nbmax + (s - m.x));
-            ++cnt; ++hi;
-          } else {
-            const int t0 = ch * TCH;
-            const int nrows = min(TCH, T - t0) * r;
-            const size_t row0 = ((size_t)b * T + t0) * r;
-            while (j0 < nrows && cnt <= RED_CAP - 64) {
-              const int j = j0 + lane;
-              const bool match = j < nrows && ranges[row0 + j] == s;
-              const unsigned long long mask = __ballot(match);
-              if (match) items[cnt + __popcll(mask & lt)] = 0x80000000u | (unsigned)(row0 + j);
-              cnt += __popcll(mask);
-              j0 += 64;
-            }
-            if (j0 >= nrows) { ++hi; j0 = 0; }
+    int hi = 0, j0 = 0;
+    while (hi < nh) {
+      int cnt = 0;
+      while (hi < nh && cnt <= RED_CAP - 128) {
+        const int ch = hits[3 * hi], mx = hits[3 * hi + 1], my = hits[3 * hi + 2];
+        if (my > 0) {
+          if (lane == 0) items[cnt] = (unsigned)(((size_t)b * nchunks + ch) * nbmax + (s - mx));
+          ++cnt; ++hi;
+        } else {
+          const int t0 = ch * TCH;
+          const int nrows = min(TCH, T - t0) * r;
+          const size_t row0 = ((size_t)b * T + t0) * r;
+          while (j0 < nrows && cnt <= RED_CAP - 128) {
+            const int ja = j0 + lane, jb = j0 + 64 + lane;          // two independent loads per pass
+            const int va = ja < nrows ? ranges[row0 + ja] : -1;
+            const int vb = jb < nrows ? ranges[row0 + jb] : -1;
+            const unsigned long long ma = __ballot(va == s), mk = __ballot(vb == s);
+            if (va == s) items[cnt + __popcll(ma & lt)] = 0x80000000u | (unsigned)(row0 + ja);
+            cnt += __popcll(ma);
+            if (vb == s) items[cnt + __popcll(mk & lt)] = 0x80000000u | (unsigned)(row0 + jb);
+            cnt += __popcll(mk);
+            j0 += 128;
           }
+          if (j0 >= nrows) { ++hi; j0 = 0; }
         }
-        if (lane == 0) { sh_nitems = cnt; sh_hi = hi; sh_j0 = j0; sh_done = (hi >= nh); }
       }
-      __syncthreads();
-      const int n = sh_nitems;
-      const int done = sh_done;
-      for (int i = 0; i < n; ++i) {
+      // LDS writes above are visible to the whole wave after the waitcnt the compiler places before the reads below
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int i = 0;
+      for (; i + 3 < cnt; i += 4) {
+        const float* src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned it = items[i + u];
+          src[u] = (it & 0x80000000u) ? g_lm_p + (size_t)(it & 0x7fffffffu) * C : partial + (size_t)it * C;
+        }
+        f4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c4 = cb + lane + 64 * q;
+            v[u][q] = (c4 < n4) ? (f4)reinterpret_cast<const f4u*>(src[u])[c4] : f4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += v[u][q];
+      }
+      for (; i < cnt; ++i) {
         const unsigned it = items[i];
         const float* src = (it & 0x80000000u) ? g_lm_p + (size_t)(it & 0x7fffffffu) * C : partial + (size_t)it * C;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c4 = cb + threadIdx.x + 128 * q;
+          const int c4 = cb + lane + 64 * q;
           if (c4 < n4) acc[q] += reinterpret_cast<const f4u*>(src)[c4];
         }
       }
-      __syncthreads();
-      if (done) break;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int c4 = cb + threadIdx.x + 128 * q;
-      if (c4 < n4) reinterpret_cast<f4u*>(d_lm + ((size_t)b * S1 + s) * C)[c4] = acc[q];
-    }
-    if (cb + 512 < n4) {   // another column sweep: restart the item stream
-      __syncthreads();
-      if (threadIdx.x == 0) { sh_hi = 0; sh_j0 = 0; sh_done = 0; }
-      __syncthreads();
+      const int c4 = cb + lane + 64 * q;
+      if (c4 < n4) reinterpret_cast<f4u*>(out)[c4] = acc[q];
     }
   }
 }
@@ -581,7 +597,7 @@ int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* r
   }
   int rc = check_launch("do_pruning_bwd_chunk");
   if (rc != FTR_OK) return rc;
-  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(128), sizeof(int) * (size_t)nchunks, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, nbmax, nchunks);
+  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(64), 3 * sizeof(int) * (size_t)nchunks, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, nbmax, nchunks);
   return check_launch("do_pruning_bwd_reduce");
 }
 
