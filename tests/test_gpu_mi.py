@@ -42,7 +42,7 @@ def test_selftest(ft, dev):
 
 @pytest.mark.parametrize("impl", ["wavefront", "plain", "mono", "duo", "chain"])
 @pytest.mark.parametrize("modified", [False, True])
-@pytest.mark.parametrize("shape", [(2, 4, 8), (3, 1, 1), (3, 7, 10), (4, 50, 200), (2, 63, 70), (2, 64, 65),
+@pytest.mark.parametrize("shape", [(2, 0, 5), (2, 5, 1), (1, 0, 1), (2, 1, 40), (2, 4, 8), (3, 1, 1), (3, 7, 10), (4, 50, 200), (2, 63, 70), (2, 64, 65),
                                    (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40), (2, 383, 150), (2, 400, 130), (1, 1100, 70)])
 def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
     B, S, T = shape
