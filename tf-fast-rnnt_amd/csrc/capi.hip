@@ -100,7 +100,7 @@ int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (mi_impl() == 1) {
-    FTR_REQUIRE(px && py, "mutual_information_bwd: the plain family needs px and py");
+    FTR_REQUIRE((px || S == 0) && py, "mutual_information_bwd: the plain family needs px and py");
     return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
   }
   if (mi_impl() == 0) return mi_bidir_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
