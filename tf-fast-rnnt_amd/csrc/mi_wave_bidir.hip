@@ -36,7 +36,20 @@ namespace ftr {
 using namespace wavecfg;
 namespace {
 
-constexpr int NPFC = 3;          // chunks in flight in the IO wave's registers
+// Prefetch depth of the IO-in wave (chunks in flight in registers) and the back-off of a COMM wave whose granules are
+// not there yet.  Measured (profiles/r01_k_mi_prefetch_poll.log): the forward's two input streams need 4 slots of
+// lead at the ~0.75 us slots the 4-wave workgroup reaches (3 left the IO-in wave waiting on memory, 76.8 -> 62.0 us
+// at c3); the flow pass has one stream and is not helped; a short poll back-off (128 instead of 1536 cycles) trims the
+// detection delay of every band hop.
+#ifndef FTR_NPF_FWD
+#define FTR_NPF_FWD 4
+#endif
+#ifndef FTR_NPF_FLOW
+#define FTR_NPF_FLOW 3
+#endif
+#ifndef FTR_POLL_SLEEP
+#define FTR_POLL_SLEEP 2
+#endif
 constexpr int kMaxSpin = 400000; // polls of ~1 us before a band gives up (never reached unless a producer died)
 typedef unsigned long long u64;
 
@@ -82,7 +95,7 @@ __device__ __forceinline__ bool comm_import(float* in_ring, const u64* gran_in, 
     const bool ok = (unsigned)(g >> 32) == (unsigned)(m + 1);
     if (__all(ok)) break;                 // wave-uniform exit
     if (spins >= kMaxSpin) return false;  // wave-uniform (spins is uniform)
-    __builtin_amdgcn_s_sleep(24);
+    __builtin_amdgcn_s_sleep(FTR_POLL_SLEEP);
     g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane < CH) in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
@@ -118,7 +131,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
                                                int Tg, int S, int T, int jstop) {
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
-  constexpr int NPF = NPFC;
+  constexpr int NPF = FTR_NPF_FWD;
   constexpr int LOOK = MOD ? 1 : 5;  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK
   constexpr int PRE = NPF + 1;       // IO pipeline warm-up slots in front of chunk 0
   const int lane = threadIdx.x & 63;
@@ -578,7 +591,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
                                                 int S, int T, int jinj) {
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
-  constexpr int NPF = NPFC;
+  constexpr int NPF = FTR_NPF_FLOW;
   constexpr int LOOK = MOD ? 1 : 5;
   constexpr int PRE = NPF + 1;
   const int lane = threadIdx.x & 63;
