@@ -615,6 +615,14 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   const int nslots = (nchunks - kfirst) + PRE + 1;
   const int NIT = (nslots + NPF - 1) / NPF;
   const int base = kfirst - PRE;
+#ifdef FTR_STAMP_FLOW
+  FTR_SYNC_DECL;
+#define FTR_FSYNC() FTR_SYNC()
+#define FTR_FREPORT(slot) do { if (REVM && b == 0 && w == FTR_STAMP_BAND && lane == 0) { g_stamps[4 * (slot)] = st_busy; g_stamps[4 * (slot) + 1] = st_wait; g_stamps[4 * (slot) + 2] = st_n; } } while (0)
+#else
+#define FTR_FSYNC() __syncthreads()
+#define FTR_FREPORT(slot) do { } while (0)
+#endif
 
   if (wid == 0) {
     // ======================================================================= COMPUTE wave
@@ -685,8 +693,9 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           compute_chunk(kc, std::false_type{});
         }
       }
-      __syncthreads();
+      FTR_FSYNC();
     }
+    FTR_FREPORT(0);
     return;
   }
 
@@ -710,8 +719,9 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
         }
       }
       g_cur = g_next;
-      __syncthreads();
+      FTR_FSYNC();
     }
+    FTR_FREPORT(2);
     return;
   }
 
@@ -875,8 +885,9 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
         if (k >= K0d && k < K1) drain_fast(k);   // wave-uniform
         else drain_general(k);
       }
-      __syncthreads();
+      FTR_FSYNC();
     }
+    FTR_FREPORT(3);
     return;
   }
 
@@ -884,12 +895,12 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   auto slot_general = [&](int kc, f4 (&gq)[4]) {
     if (kc + 1 >= kfirst && kc + 1 < nchunks) park(kc + 1, gq);
     if (kc + 1 + NPF >= kfirst && kc + 1 + NPF < nchunks) load_general(kc + 1 + NPF, gq);
-    __syncthreads();
+    FTR_FSYNC();
   };
   auto slot_fast = [&](int kc, f4 (&gq)[4]) {
     park(kc + 1, gq);
     load_fast(kc + 1 + NPF, gq);
-    __syncthreads();
+    FTR_FSYNC();
   };
 
   // fast slot kc: loaded chunk kc+1+NPF interior (and not before the cut's chunk), parked chunk kc+1 exists
@@ -915,7 +926,10 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 #pragma unroll
     for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
   }
+  FTR_FREPORT(1);
 }
+#undef FTR_FSYNC
+#undef FTR_FREPORT
 
 #undef FTR_TG
 #undef FTR_TPX
