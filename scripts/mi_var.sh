@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for v in "" F5 F4S8 F5S1; do
+for v in ""; do
   if [ -z "$v" ]; then unset FTR_LIB_PATH; else export FTR_LIB_PATH=$PWD/gpurun_exp/libftr_$v.so; fi
   echo "== variant ${v:-product}"
   for shape in "32 200 1000" "32 63 1000" "8 1000 8000"; do timeout -k 10 120 python scripts/mi_bench.py $shape 2>&1 | grep "warm" | head -1; done

@@ -448,9 +448,15 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   auto drain_fast = [&](int k) {
     const f4* sD = FTR_TD(k);
     float* ws_k = REVM ? wsb - CH * k : wsb + CH * k;
+    f4 v[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v[m] = sD[fq * PLANE + 16 * m + frow];
+    // all LDS reads are issued before the first predicated store: left to itself the compiler sinks each read into
+    // its store's exec-masked block and waits for them one at a time (seen in the ISA: 8 serial LDS round trips)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const f4 g = to_G(sD[fq * PLANE + 16 * m + frow]);
+      const f4 g = to_G(v[m]);
       if (rvalid[m]) *reinterpret_cast<f4u*>(ws_k + offG[m]) = REVM ? rev4(g) : g;
     }
   };
@@ -864,12 +870,17 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     const f4* sY = FTR_TPY(k);
     float* px_k = REVM ? pxg - CH * k : pxg + CH * k;
     float* py_k = REVM ? pyg - CH * k : pyg + CH * k;
+    f4 gx[4], gy[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const f4 gx = sX[fq * PLANE + 16 * m + frow];
-      const f4 gy = sY[fq * PLANE + 16 * m + frow];
-      if (xvalid[m]) *reinterpret_cast<f4u*>(px_k + offPX[m]) = REVM ? rev4(gx) : gx;
-      if (rvalid[m]) *reinterpret_cast<f4u*>(py_k + offPY[m]) = REVM ? rev4(gy) : gy;
+      gx[m] = sX[fq * PLANE + 16 * m + frow];
+      gy[m] = sY[fq * PLANE + 16 * m + frow];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all eight LDS reads in flight together, see the forward body
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (xvalid[m]) *reinterpret_cast<f4u*>(px_k + offPX[m]) = REVM ? rev4(gx[m]) : gx[m];
+      if (rvalid[m]) *reinterpret_cast<f4u*>(py_k + offPY[m]) = REVM ? rev4(gy[m]) : gy[m];
     }
   };
 
