@@ -197,7 +197,7 @@ def test_full_size_pruned_step_properties(ft, dev):
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
-@pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7)])
+@pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7), (2, 37, 9, 700), (1, 21, 4, 641)])
 def test_native_simple_builder_forward_backward(ft, dev, oracle, rnnt_type, cfg):
     """get_rnnt_logprobs (native prologue/epilogue kernels around the GEMM): px/py against the oracle with the exact
     -inf pattern; d/d am and d/d lm against float64 autograd through the op-by-op torch restatement."""
@@ -239,7 +239,7 @@ def test_native_simple_builder_odd_vocab_and_penalty(ft, dev, oracle):
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
 @pytest.mark.parametrize("scales", [(0.1, 0.2), (0.0, 0.0), (0.25, 0.0)])
-@pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7)])
+@pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7), (2, 37, 9, 644)])
 def test_native_smoothed_builder_forward_backward(ft, dev, oracle, rnnt_type, scales, cfg):
     """get_rnnt_logprobs_smoothed on the native builder kernels (rnnt_loss.py:1132-1367): px/py against the oracle
     with the exact -inf pattern (tolerance 2e-5 absolute/relative: f32 sums in a different order); d/d am and d/d lm

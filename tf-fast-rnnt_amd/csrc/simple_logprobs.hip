@@ -21,7 +21,8 @@ namespace ftr {
 namespace {
 
 constexpr float kTiny = 1.401298464324817e-45f;  // tf.math.nextafter(0., 1.)  (rnnt_loss.py:181)
-constexpr int TT = 32;                           // frames per tile
+constexpr int kTTwide = 32;                      // frames per tile while [TT][C+1] floats fit twice in a CU's LDS (C <= 608)
+constexpr int kTTnarrow = 16;                    // ... and for larger vocabularies (two workgroups per CU again)
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -69,8 +70,8 @@ __global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict
   if (lane == 0) rowmax[row] = m;
 }
 
-// grid (ceil(T1 / TT), B); block 256 = 8 row-groups x 32 frames.  LDS: am tile [TT][C+1].
-template <bool MOD>
+// grid (ceil(T1 / TT), B); block 256 = (256/TT) row-groups x TT frames.  LDS: am tile [TT][C+1].
+template <bool MOD, int TT>
 __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __restrict__ lm,
                                   const int32_t* __restrict__ symbols, const float* __restrict__ prod,
                                   const float* __restrict__ am_max, const float* __restrict__ lm_max,
@@ -128,7 +129,8 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   }
   __syncthreads();
   const int tx = threadIdx.x & (TT - 1);
-  const int ty = threadIdx.x >> 5;
+  constexpr int NY = 256 / TT;
+  const int ty = threadIdx.x / TT;
   const int t = t0 + tx;
   const int te = boundary ? boundary[4 * b + 3] : T;
   const float amx = (t < T) ? am_max[(size_t)b * T + t] : 0.0f;
@@ -139,7 +141,7 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   const float ulog_blank = smooth ? ulog[blank] : 0.0f;
   const float* prodb = prod + (size_t)b * (S + 1) * T + t;
 #pragma unroll 4
-  for (int s = ty; s <= S; s += 8) {
+  for (int s = ty; s <= S; s += NY) {
     float nrm = 0.0f;
     const float lon = rs_lon[s];
     if (t < T) {
@@ -196,9 +198,9 @@ __global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* 
   }
 }
 
-// grid (ceil(T / TT), B); block 256 = 8 column-owner groups x 32 frames.  LDS: acc [TT][C + 1] + csy[8][TT].
+// grid (ceil(T / TT), B); block 256 = (256/TT) column-owner groups x TT frames.  LDS: acc [TT][C + 1] + csy/csx [256].
 // Thread (ty, tx) owns the accumulator cells acc[tx][c] with c % 8 == ty: every cell has one owner.
-template <bool MOD>
+template <bool MOD, int TT>
 __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy, const Scale scale,
                                      const float* __restrict__ damp, const float* __restrict__ am_probs,
                                      const int32_t* __restrict__ symbols, const int32_t* __restrict__ boundary,
@@ -214,11 +216,12 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   const int T1 = MOD ? T : T + 1;
   const int ld = C + 1;
   float* csy = acc + TT * ld;
-  float* csx = csy + 8 * TT;
+  constexpr int NY = 256 / TT;       // thread rows = symbol classes (sym % NY)
+  float* csx = csy + NY * TT;
   for (int i = threadIdx.x; i < TT * ld; i += blockDim.x) acc[i] = 0.0f;
   __syncthreads();
   const int tx = threadIdx.x & (TT - 1);
-  const int ty = threadIdx.x >> 5;
+  const int ty = threadIdx.x / TT;
   const int t = t0 + tx;
   const int te = boundary ? boundary[4 * b + 3] : T;
   const bool tok = t < T;
@@ -227,14 +230,15 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   // rows grouped by symbol class: thread row ty owns the columns with sym % 8 == ty (no two threads ever touch the
   // same accumulator, rows are added in ascending s: deterministic).  Each 32-thread row first builds the ordered
   // list of its rows in LDS (ballot compaction), then sweeps only those -- S/8 iterations instead of S.
-  unsigned short* slist = reinterpret_cast<unsigned short*>(csx + 8 * TT) + (size_t)ty * S;
+  unsigned short* slist = reinterpret_cast<unsigned short*>(csx + NY * TT) + (size_t)ty * S;
   int cnt = 0;
   {
-    const int hshift = 32 * (ty & 1);   // which half of the wave this thread row is
-    for (int s0 = 0; s0 < S; s0 += 32) {
+    const int hshift = TT * (ty % (64 / TT));   // which part of the wave this thread row is
+    constexpr unsigned kRowMask = (TT == 32) ? 0xffffffffu : ((1u << (TT & 31)) - 1u);
+    for (int s0 = 0; s0 < S; s0 += TT) {
       const int s = s0 + tx;
-      const bool mine = s < S && (symb[s] & 7) == ty;
-      const unsigned m32 = (unsigned)(__ballot(mine) >> hshift);
+      const bool mine = s < S && (symb[s] & (NY - 1)) == ty;
+      const unsigned m32 = (unsigned)(__ballot(mine) >> hshift) & kRowMask;
       if (mine) slist[cnt + __popc(m32 & ((1u << tx) - 1u))] = (unsigned short)s;
       cnt += __popc(m32);
     }
@@ -263,7 +267,7 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   if (tok) {
     const float* ycol = gpy + (size_t)b * (S + 1) * T + t;
 #pragma unroll 4
-    for (int s = ty; s <= S; s += 8) cs += ycol[(size_t)s * T] * sc;
+    for (int s = ty; s <= S; s += NY) cs += ycol[(size_t)s * T] * sc;
   }
   csy[ty * TT + tx] = cs;
   csx[ty * TT + tx] = cx;
@@ -275,7 +279,7 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
       if (t0 + tt >= T) continue;
       float col = 0.0f, colx = 0.0f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) { col += csy[g * TT + tt]; colx += csx[g * TT + tt]; }
+      for (int g = 0; g < NY; ++g) { col += csy[g * TT + tt]; colx += csx[g * TT + tt]; }
       const size_t o = ((size_t)b * T + t0 + tt) * C;
       const float* arow = acc + tt * ld;
       float R = 0.0f;
@@ -362,18 +366,22 @@ int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols
                         double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog,
                         float cs, float ls, float as, float* px, float* py, int B, int T, int S, int C, int modified,
                         hipStream_t st) {
+  const int T1 = modified ? T : T + 1;
+  const bool narrow = C > 608;      // [32][C+1] floats no longer fit twice in 160 KB of LDS
+  const int TT = narrow ? kTTnarrow : kTTwide;
   const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 6 * (size_t)(S + 1));
   int rc = tile_lds_ok(lds, "simple_logprobs_fwd");
   if (rc != FTR_OK) return rc;
-  const int T1 = modified ? T : T + 1;
   const dim3 grid((T1 + TT - 1) / TT, B);
-  if (modified) {
-    if ((rc = reserve_lds(simple_fwd_kernel<true>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_fwd_kernel<true>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm, amonly_norm, ulog, cs, ls, as, px, py, T, S, C);
-  } else {
-    if ((rc = reserve_lds(simple_fwd_kernel<false>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_fwd_kernel<false>, grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm, amonly_norm, ulog, cs, ls, as, px, py, T, S, C);
-  }
+#define FTR_LAUNCH_FWD(MODV, TTV)                                                                                       \
+  do {                                                                                                                  \
+    if ((rc = reserve_lds(simple_fwd_kernel<MODV, TTV>, lds, "simple_logprobs_fwd")) != FTR_OK) return rc;              \
+    hipLaunchKernelGGL((simple_fwd_kernel<MODV, TTV>), grid, dim3(256), lds, st, am, lm, symbols, prod, am_max, lm_max, \
+                       boundary, blank, delay_penalty, lmonly_norm, amonly_norm, ulog, cs, ls, as, px, py, T, S, C);    \
+  } while (0)
+  if (modified) { if (narrow) FTR_LAUNCH_FWD(true, kTTnarrow); else FTR_LAUNCH_FWD(true, kTTwide); }
+  else { if (narrow) FTR_LAUNCH_FWD(false, kTTnarrow); else FTR_LAUNCH_FWD(false, kTTwide); }
+#undef FTR_LAUNCH_FWD
   return check_launch("simple_logprobs_fwd");
 }
 
@@ -390,17 +398,21 @@ int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, cons
                            const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C,
                            int modified, hipStream_t st) {
   if (S > 65535) { set_error("simple_logprobs_bwd_am: S = %d > 65535 is not supported", S); return FTR_ERR_UNSUPPORTED; }
-  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 16 * TT) + sizeof(unsigned short) * 8 * (size_t)S;
+  const bool narrow = C > 608;
+  const int TT = narrow ? kTTnarrow : kTTwide;
+  const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 2 * 256) + sizeof(unsigned short) * (256 / TT) * (size_t)S;
   int rc = tile_lds_ok(lds, "simple_logprobs_bwd_am");
   if (rc != FTR_OK) return rc;
   const dim3 grid((T + TT - 1) / TT, B);
-  if (modified) {
-    if ((rc = reserve_lds(simple_bwd_am_kernel<true>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_bwd_am_kernel<true>, grid, dim3(256), lds, st, gpx, gpy, scale, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
-  } else {
-    if ((rc = reserve_lds(simple_bwd_am_kernel<false>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;
-    hipLaunchKernelGGL(simple_bwd_am_kernel<false>, grid, dim3(256), lds, st, gpx, gpy, scale, damp, am_probs, symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
-  }
+#define FTR_LAUNCH_AM(MODV, TTV)                                                                                        \
+  do {                                                                                                                  \
+    if ((rc = reserve_lds(simple_bwd_am_kernel<MODV, TTV>, lds, "simple_logprobs_bwd_am")) != FTR_OK) return rc;        \
+    hipLaunchKernelGGL((simple_bwd_am_kernel<MODV, TTV>), grid, dim3(256), lds, st, gpx, gpy, scale, damp, am_probs,    \
+                       symbols, boundary, blank, kdir, uvec, amdot, as, Rout, d_am, T, S, C);                           \
+  } while (0)
+  if (modified) { if (narrow) FTR_LAUNCH_AM(true, kTTnarrow); else FTR_LAUNCH_AM(true, kTTwide); }
+  else { if (narrow) FTR_LAUNCH_AM(false, kTTnarrow); else FTR_LAUNCH_AM(false, kTTwide); }
+#undef FTR_LAUNCH_AM
   return check_launch("simple_logprobs_bwd_am");
 }
 
