@@ -21,8 +21,12 @@ namespace ftr {
 namespace {
 
 constexpr float kTiny = 1.401298464324817e-45f;  // tf.math.nextafter(0., 1.)  (rnnt_loss.py:181)
-constexpr int kTTwide = 32;                      // frames per tile while [TT][C+1] floats fit twice in a CU's LDS (C <= 608)
-constexpr int kTTnarrow = 16;                    // ... and for larger vocabularies (two workgroups per CU again)
+#ifndef FTR_TT_NARROW_ABOVE
+#define FTR_TT_NARROW_ABOVE 300
+#endif
+constexpr int kTTwide = 32;                      // frames per tile for small vocabularies
+constexpr int kTTnarrow = 16;                    // above FTR_TT_NARROW_ABOVE columns: more workgroups per CU (LDS) beats longer
+                                                 // row segments (measured at C = 500: fwd 60 -> 47 us, bwd_am 73 -> 65 us; C = 1024: 374 -> 242, 546 -> 420)
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -367,7 +371,7 @@ int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols
                         float cs, float ls, float as, float* px, float* py, int B, int T, int S, int C, int modified,
                         hipStream_t st) {
   const int T1 = modified ? T : T + 1;
-  const bool narrow = C > 608;      // [32][C+1] floats no longer fit twice in 160 KB of LDS
+  const bool narrow = C > FTR_TT_NARROW_ABOVE;
   const int TT = narrow ? kTTnarrow : kTTwide;
   const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 6 * (size_t)(S + 1));
   int rc = tile_lds_ok(lds, "simple_logprobs_fwd");
@@ -398,7 +402,7 @@ int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, cons
                            const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C,
                            int modified, hipStream_t st) {
   if (S > 65535) { set_error("simple_logprobs_bwd_am: S = %d > 65535 is not supported", S); return FTR_ERR_UNSUPPORTED; }
-  const bool narrow = C > 608;
+  const bool narrow = C > FTR_TT_NARROW_ABOVE;
   const int TT = narrow ? kTTnarrow : kTTwide;
   const size_t lds = sizeof(float) * ((size_t)TT * (C + 1) + 2 * 256) + sizeof(unsigned short) * (256 / TT) * (size_t)S;
   int rc = tile_lds_ok(lds, "simple_logprobs_bwd_am");
