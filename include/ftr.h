@@ -48,10 +48,11 @@ const char* ftr_last_error(void);
 int ftr_set_mi_impl(int impl);
 int ftr_get_mi_impl(void);
 
-/* Number of floats of fwd->bwd workspace (`p` below) for a problem size: B*(S+1)*(T+1) -- the shape of the
- * reference's temp `p` (tf_fast_rnnt_op.cc:65-67) -- plus a small inter-workgroup hand-off region.  Its CONTENT
- * is implementation defined: the same buffer must be handed unchanged from _fwd to _bwd (the
- * backward reuses the hand-off region as scratch).  Must be 8-byte aligned. */
+/* Number of floats of fwd->bwd workspace (`p` below) for a problem size: about two lattices of the shape of the
+ * reference's temp `p` (tf_fast_rnnt_op.cc:65-67; one split-ratio lattice per direction of the recursion), the
+ * values on the cut, and a small inter-workgroup hand-off region.  Its CONTENT is implementation defined (see
+ * DESIGN.md section 4): the same buffer must be handed unchanged from _fwd to _bwd (the backward reuses the hand-off
+ * region as scratch).  Must be 16-byte aligned. */
 size_t ftr_mutual_information_workspace_floats(int B, int S, int T);
 
 /*
