@@ -168,38 +168,54 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   }
 }
 
-// one workgroup per (b, s) row: W[b,s,:] and the two row sums.  rsx[b,s] = sum_t gpx'[b,s,t] (0 for s == S),
-// rsy[b,s] = sum_t gpy[b,s,t]; gpx' = gpx with the overwritten cells (t == T, t == t_end) masked.
+// one WAVE per (b, s) row (four rows per workgroup, no barrier): W[b,s,:] and the two row sums.
+// rsx[b,s] = sum_t gpx'[b,s,t] (0 for s == S), rsy[b,s] = sum_t gpy[b,s,t]; gpx' = gpx with the overwritten cells
+// (t == T, t == t_end) masked.  Rows are only 4-byte aligned (T+1 columns): 16-byte accesses through f4u.
 template <bool MOD>
-__global__ void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy, const Scale scale,
-                                    const float* __restrict__ prod, const int32_t* __restrict__ boundary,
-                                    float* __restrict__ W, float* __restrict__ rsx, float* __restrict__ rsy,
-                                    float cs, int T, int S) {
-  __shared__ float red[2][4];
-  const int s = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(256) void simple_bwd_w_kernel(const float* __restrict__ gpx, const float* __restrict__ gpy,
+                                                           const Scale scale, const float* __restrict__ prod,
+                                                           const int32_t* __restrict__ boundary, float* __restrict__ W,
+                                                           float* __restrict__ rsx, float* __restrict__ rsy, float cs,
+                                                           int T, int S, int B) {
+  const int lane = threadIdx.x & 63;
+  const size_t rowid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // b * (S+1) + s
+  if (rowid >= (size_t)B * (S + 1)) return;
+  const int b = (int)(rowid / (S + 1));
+  const int s = (int)(rowid - (size_t)b * (S + 1));
   const int T1 = MOD ? T : T + 1;
   const int te = boundary ? boundary[4 * b + 3] : T;
-  const size_t rowy = ((size_t)b * (S + 1) + s) * T;
+  const size_t rowy = rowid * T;
   const size_t rowx = ((size_t)b * S + s) * T1;
-  float sx = 0.0f, sy = 0.0f;
   const float sc = scale.at(b);
-  for (int t = threadIdx.x; t < T; t += blockDim.x) {
-    float gx = 0.0f;
-    if (s < S && (MOD || t != te)) gx = gpx[rowx + t] * sc;
-    const float gy = gpy[rowy + t] * sc;
-    sx += gx; sy += gy;
-    W[rowy + t] = -cs * (gx + gy) / (prod[rowy + t] + kTiny);   // cs = 1 for the simple loss
+  const bool hasx = s < S;
+  float sx = 0.0f, sy = 0.0f;
+  const int n4 = T >> 2;
+  for (int q = lane; q < n4; q += 64) {
+    const int t = 4 * q;
+    f4 gx = {0.f, 0.f, 0.f, 0.f};
+    if (hasx) gx = *reinterpret_cast<const f4u*>(gpx + rowx + t);
+    const f4 gy = *reinterpret_cast<const f4u*>(gpy + rowy + t);
+    const f4 pr = *reinterpret_cast<const f4u*>(prod + rowy + t);
+    f4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = gx[e] * sc;
+      if (!MOD && t + e == te) x = 0.0f;
+      const float y = gy[e] * sc;
+      sx += x; sy += y;
+      w[e] = -cs * (x + y) / (pr[e] + kTiny);   // cs = 1 for the simple loss
+    }
+    *reinterpret_cast<f4u*>(W + rowy + t) = w;
+  }
+  for (int t = 4 * n4 + lane; t < T; t += 64) {
+    float x = 0.0f;
+    if (hasx && (MOD || t != te)) x = gpx[rowx + t] * sc;
+    const float y = gpy[rowy + t] * sc;
+    sx += x; sy += y;
+    W[rowy + t] = -cs * (x + y) / (prod[rowy + t] + kTiny);
   }
   sx = wave_sum(sx); sy = wave_sum(sy);
-  const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[0][wv] = sx; red[1][wv] = sy; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float a = 0.0f, c = 0.0f;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += red[0][i]; c += red[1][i]; }
-    rsx[(size_t)b * (S + 1) + s] = a;
-    rsy[(size_t)b * (S + 1) + s] = c;
-  }
+  if (lane == 0) { rsx[rowid] = sx; rsy[rowid] = sy; }
 }
 
 // grid (ceil(T / TT), B); block 256 = (256/TT) column-owner groups x TT frames.  LDS: acc [TT][C + 1] + csy/csx [256].
@@ -391,9 +407,10 @@ int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols
 
 int simple_logprobs_bwd_w(const float* gpx, const float* gpy, Scale scale, const float* prod, const int32_t* boundary,
                           float* W, float* rsx, float* rsy, float cs, int B, int T, int S, int modified, hipStream_t st) {
-  const dim3 grid(S + 1, B);
-  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, scale, prod, boundary, W, rsx, rsy, cs, T, S);
-  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, scale, prod, boundary, W, rsx, rsy, cs, T, S);
+  const size_t rows = (size_t)B * (S + 1);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (modified) hipLaunchKernelGGL(simple_bwd_w_kernel<true>, grid, dim3(256), 0, st, gpx, gpy, scale, prod, boundary, W, rsx, rsy, cs, T, S, B);
+  else hipLaunchKernelGGL(simple_bwd_w_kernel<false>, grid, dim3(256), 0, st, gpx, gpy, scale, prod, boundary, W, rsx, rsy, cs, T, S, B);
   return check_launch("simple_logprobs_bwd_w");
 }
 
