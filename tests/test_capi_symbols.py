@@ -74,3 +74,15 @@ def test_argument_validation_without_device(ft):
     assert L.ftr_prune_ranges_i32(None, None, None, None, None, 0, 10, 20, 21, 50, ctypes.byref(r), None) == 1
     assert r.value == 11                                       # s_range > S  ->  S + 1  (rnnt_loss.py:710-711)
     assert L.ftr_prune_ranges_i32(None, None, None, None, None, 0, 10, 20, 25, 5, None, None) == 0
+
+
+def test_header_is_plain_c():
+    """include/ftr.h is the drop-in boundary: it must parse as C99 and as C++ on its own (no HIP, no torch)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "ftr.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", hdr])
+    subprocess.check_call(["g++", "-x", "c++", "-Wall", "-Werror", "-fsyntax-only", hdr])
