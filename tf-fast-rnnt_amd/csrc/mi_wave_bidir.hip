@@ -79,13 +79,6 @@ __host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
 }
 
 // COMM wave helpers (see mi_wave_chain.hip) -----------------------------------------------------------------
-__device__ __forceinline__ void comm_publish(const float* out_ring, u64* gran_out, int m, int lane) {
-  if (lane < CH) {
-    const float v = out_ring[(CH * m + lane) & (RINGN - 1)];
-    const u64 g = ((u64)(unsigned)(m + 1) << 32) | (u64)__float_as_uint(v);
-    __hip_atomic_store(gran_out + CH * m + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 __device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
   return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -586,6 +579,7 @@ __global__ __launch_bounds__(256) void mi_bidir_mid_kernel(const int32_t* __rest
 #define FTR_TG(k) (lds + ((k) & 1) * TILE_F4)
 #define FTR_TPX(k) (lds + (2 + ((k) & 1)) * TILE_F4)
 #define FTR_TPY(k) (lds + (4 + ((k) & 1)) * TILE_F4)
+#define FTR_TXO(k) (lds + (6 + ((k) & 1)) * TILE_F4)
 
 // One direction of one band of the backward pass.  REVM = true: from the cut back to the origin (alpha half),
 // REVM = false: from the cut forward to the end cell (beta half).  jinj = walk step of the cut in this direction.
@@ -607,9 +601,8 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   const int NWact = (Sn + 63) >> 6;
 
   f4* lds = reinterpret_cast<f4*>(smem);
-  float* in_ring = reinterpret_cast<float*>(lds + 6 * TILE_F4);
-  float* out_ring = in_ring + RINGN;
-  for (int i = threadIdx.x; i < 2 * RINGN; i += blockDim.x) in_ring[i] = 0.0f;
+  float* in_ring = reinterpret_cast<float*>(lds + 8 * TILE_F4);   // tiles: G, PX, PY, XO (two of each)
+  for (int i = threadIdx.x; i < RINGN; i += blockDim.x) in_ring[i] = 0.0f;
   __syncthreads();
 
   const int nchunks = (Tn + 63 * SKEW + CH - 1) / CH;
@@ -630,13 +623,14 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 #define FTR_FREPORT(slot) do { } while (0)
 #endif
 
+  const int wfin = (Sn - 1) >> 6, lfin = (Sn - 1) & 63;
+  // REVM: the walk ends at the origin, where p_grad[s_begin,t_begin] appears (the ans_grad self check)
+  const int jfin = (REVM && w == wfin) ? (Tn - 1 + SKEW * lfin) : -1000;
+
   if (wid == 0) {
     // ======================================================================= COMPUTE wave
+    // (as in the forward body: arithmetic only; the three per-cell outputs leave through LDS tiles)
     const f4* ring_in = reinterpret_cast<const f4*>(in_ring);
-    f4* ring_out = reinterpret_cast<f4*>(out_ring);
-    const int wfin = (Sn - 1) >> 6, lfin = (Sn - 1) & 63;
-    // REVM: the walk ends at the origin, where p_grad[s_begin,t_begin] appears (the ans_grad self check)
-    const int jfin = (REVM && w == wfin) ? (Tn - 1 + SKEW * lfin) : -1000;
     // occupancy of this lane's cut cell, scaled by the incoming gradient
     float inj = 0.0f;
     {
@@ -650,6 +644,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       const f4* cG = FTR_TG(k);
       f4* cPX = FTR_TPX(k);
       f4* cPY = FTR_TPY(k);
+      f4* cXO = FTR_TXO(k);
       f4 Gn = cG[lane];
       f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];
 #pragma unroll
@@ -660,7 +655,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           Gn = cG[(q + 1) * PLANE + lane];
           En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
         }
-        f4 XO4, PX4, PY4, PG4;
+        f4 XO4, PX4, PY4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float ev = (e == 0) ? ecarry : E4[e - 1];
@@ -669,7 +664,6 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           if (INJ && j0 + e == jli) pg += inj;    // the cut: nothing has flowed yet, the occupancy enters here
           PX4[e] = xin;    // flow through the px transition between this cell and its walk predecessor row
           PY4[e] = yprev;  // flow through the py transition between this cell and its walk predecessor column
-          PG4[e] = pg;     // occupancy of the cell
           // steps in front of the cut (first chunk only) lie in the other half: their ratios were never computed
           // (uninitialised memory, possibly NaN), so the zero flow there is forced rather than multiplied
           const bool pre = INJ && (j0 + e < jli);
@@ -680,12 +674,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
         ecarry = E4[3];
         cPX[q * PLANE + lane] = PX4;
         cPY[q * PLANE + lane] = PY4;
-        if (lane == 63) ring_out[(j0 & (RINGN - 1)) >> 2] = XO4;
-        if (overwrite && ans_grad && (jfin >> 2) == (j0 >> 2)) {
-          const int e = jfin & 3;
-          const float v = (e == 0) ? PG4[0] : (e == 1) ? PG4[1] : (e == 2) ? PG4[2] : PG4[3];
-          if (lane == lfin) ans_grad[b] = v;
-        }
+        cXO[q * PLANE + lane] = XO4;
       }
     };
 
@@ -702,32 +691,6 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       FTR_FSYNC();
     }
     FTR_FREPORT(0);
-    return;
-  }
-
-  if (wid == 2) {
-    // ======================================================================= COMM wave
-    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
-    const u64* gran_in = gran_b + (size_t)w * Tg;
-    const bool has_up = w > 0, has_down = w + 1 < NWact;
-    bool dead = false;
-    u64 g_cur = 0;
-    for (int gg = 0; gg < NIT * NPF; ++gg) {
-      const int kc = base + gg;
-      if (has_down && kc - 1 >= kfirst && kc - 1 < nchunks) comm_publish(out_ring, gran_out, kc - 1, lane);
-      const int m = kc + LOOK;
-      u64 g_next = 0;
-      if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
-      if (has_up && !dead && m >= kfirst_up && m < nchunks) {
-        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {
-          dead = true;
-          in_ring[lane] = __builtin_nanf("");
-        }
-      }
-      g_cur = g_next;
-      FTR_FSYNC();
-    }
-    FTR_FREPORT(2);
     return;
   }
 
@@ -774,7 +737,8 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     for (int m = 0; m < 4; ++m) dG[fq * PLANE + 16 * m + frow] = REVM ? rev4(gq[m]) : gq[m];   // REV loads stay in memory order until here
   };
   // Steps up to and including the cut (local walk step <= jli) belong to the other half and are never written.
-  auto drain_general = [&](int k) {
+  auto drain_general = [&](int k, auto xtag, auto ytag) {
+    constexpr bool DOX = decltype(xtag)::value, DOY = decltype(ytag)::value;
     const f4* sX = FTR_TPX(k);
     const f4* sY = FTR_TPY(k);
     const int jq = CH * k + 4 * fq;        // walk step of element 0
@@ -784,12 +748,13 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       const int r = row0 + row;
       if (r < Sn) {
         const int c0 = CH * k + 4 * fq - SKEW * row;
-        const f4 gx = sX[fq * PLANE + row];
-        const f4 gy = sY[fq * PLANE + row];
+        f4 gx = {0.f, 0.f, 0.f, 0.f}, gy = gx;
+        if (DOX) gx = sX[fq * PLANE + row];
+        if (DOY) gy = sY[fq * PLANE + row];
         const bool whole = jq > jli;
         if (REVM) {
           const int s = bd.se - r;
-          if (r >= 1) {  // px_grad[s][t]: rows s < se; walk columns c in [NOFF, Tn)
+          if (DOX && r >= 1) {  // px_grad[s][t]: rows s < se; walk columns c in [NOFF, Tn)
             const ptrdiff_t lo = (ptrdiff_t)s * T1 + bd.te - c0 - 3;
             if (whole && c0 >= NOFF && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pxg + lo) = rev4(gx);
@@ -799,7 +764,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
                 if (jq + e > jli && c0 + e >= NOFF && c0 + e < Tn) pxg[lo + 3 - e] = gx[e];
             }
           }
-          {  // py_grad[s][t]: columns t < te  <=>  c >= 1
+          if (DOY) {  // py_grad[s][t]: columns t < te  <=>  c >= 1
             const ptrdiff_t lo = (ptrdiff_t)s * T + bd.te - c0 - 3;
             if (whole && c0 >= 1 && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pyg + lo) = rev4(gy);
@@ -810,7 +775,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
             }
           }
         } else {
-          if (r >= 1) {  // px_grad[s-1][t + toff]: the transition INTO this cell from the row below
+          if (DOX && r >= 1) {  // px_grad[s-1][t + toff]: the transition INTO this cell from the row below
             const int cx = MOD ? c0 - 1 : c0;
             const ptrdiff_t o = (ptrdiff_t)(bd.sb + r - 1) * T1 + bd.tb + cx;
             if (whole && cx >= 0 && c0 + 3 < Tn) {
@@ -821,7 +786,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
                 if (jq + e > jli && cx + e >= 0 && c0 + e < Tn) pxg[o + e] = gx[e];
             }
           }
-          {  // py_grad[s][t-1]: the transition INTO this cell from the previous frame
+          if (DOY) {  // py_grad[s][t-1]: the transition INTO this cell from the previous frame
             const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * T + bd.tb + c0 - 1;
             if (whole && c0 >= 1 && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pyg + o) = gy;
@@ -865,7 +830,8 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       gq[m] = *reinterpret_cast<const f4u*>(ws_k + offG[m]);
     }
   };
-  auto drain_fast = [&](int k) {
+  auto drain_fast = [&](int k, auto xtag, auto ytag) {
+    constexpr bool DOX = decltype(xtag)::value, DOY = decltype(ytag)::value;
     const f4* sX = FTR_TPX(k);
     const f4* sY = FTR_TPY(k);
     float* px_k = REVM ? pxg - CH * k : pxg + CH * k;
@@ -873,28 +839,74 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     f4 gx[4], gy[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      gx[m] = sX[fq * PLANE + 16 * m + frow];
-      gy[m] = sY[fq * PLANE + 16 * m + frow];
+      if (DOX) gx[m] = sX[fq * PLANE + 16 * m + frow];
+      if (DOY) gy[m] = sY[fq * PLANE + 16 * m + frow];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all eight LDS reads in flight together, see the forward body
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all LDS reads in flight together, see the forward body
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if (xvalid[m]) *reinterpret_cast<f4u*>(px_k + offPX[m]) = REVM ? rev4(gx[m]) : gx[m];
-      if (rvalid[m]) *reinterpret_cast<f4u*>(py_k + offPY[m]) = REVM ? rev4(gy[m]) : gy[m];
+      if (DOX && xvalid[m]) *reinterpret_cast<f4u*>(px_k + offPX[m]) = REVM ? rev4(gx[m]) : gx[m];
+      if (DOY && rvalid[m]) *reinterpret_cast<f4u*>(py_k + offPY[m]) = REVM ? rev4(gy[m]) : gy[m];
     }
   };
 
   const int K0 = max(MOD ? 1 : 4, kfirst);
   const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;
 
+  const int K0d = max(MOD ? 1 : 4, kfirst + 1);     // the cut's chunk is drained with the per-step mask
+
+  if (wid == 2) {
+    // ======================================================================= COMM wave
+    // hand-off to the band below (lane 63's xout of every step, read from the XO tile), the ans_grad self check,
+    // this band's py_grad stores (the IO-out wave keeps the px_grad stores: two balanced store streams), and the
+    // import of the band above's flow.  The stores are issued before the poll, so a late producer cannot delay them.
+    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
+    const u64* gran_in = gran_b + (size_t)w * Tg;
+    const bool has_up = w > 0, has_down = w + 1 < NWact;
+    bool dead = false;
+    u64 g_cur = 0;
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int kc = base + gg;
+      const int k = kc - 1;
+      if (k >= kfirst && k < nchunks) {
+        if (has_down && lane < CH) {
+          const float* txo = reinterpret_cast<const float*>(FTR_TXO(k));
+          const float v = txo[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
+          const u64 g = ((u64)(unsigned)(k + 1) << 32) | (u64)__float_as_uint(v);
+          __hip_atomic_store(gran_out + CH * k + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (overwrite && ans_grad && k == (jfin >> 4) && lane == lfin) {   // p_grad at the origin = both inflows
+          const int idx = ((((jfin & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jfin & 3);
+          float pg = reinterpret_cast<const float*>(FTR_TPX(k))[idx] + reinterpret_cast<const float*>(FTR_TPY(k))[idx];
+          if (jfin == jli) pg += occ_b[REVM ? (Sn - 1 - (64 * w + lane)) : (64 * w + lane)] * ans_grad[b];   // one-cell lattice
+          ans_grad[b] = pg;
+        }
+        if (k >= K0d && k < K1) drain_fast(k, std::false_type{}, std::true_type{});   // wave-uniform
+        else drain_general(k, std::false_type{}, std::true_type{});
+      }
+      const int m = kc + LOOK;
+      u64 g_next = 0;
+      if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
+      if (has_up && !dead && m >= kfirst_up && m < nchunks) {
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {
+          dead = true;
+          in_ring[lane] = __builtin_nanf("");
+        }
+      }
+      g_cur = g_next;
+      FTR_FSYNC();
+    }
+    FTR_FREPORT(2);
+    return;
+  }
+
   if (wid == 3) {
-    // ------------------------------------------------------------------------- IO-out
-    const int K0d = max(MOD ? 1 : 4, kfirst + 1);     // the cut's chunk is drained with the per-step mask
+    // ------------------------------------------------------------------------- IO-out: px_grad
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int k = base + gg - 1;
       if (k >= kfirst && k < nchunks) {
-        if (k >= K0d && k < K1) drain_fast(k);   // wave-uniform
-        else drain_general(k);
+        if (k >= K0d && k < K1) drain_fast(k, std::true_type{}, std::false_type{});   // wave-uniform
+        else drain_general(k, std::true_type{}, std::false_type{});
       }
       FTR_FSYNC();
     }
@@ -945,6 +957,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 #undef FTR_TG
 #undef FTR_TPX
 #undef FTR_TPY
+#undef FTR_TXO
 
 template <bool MOD>
 __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
