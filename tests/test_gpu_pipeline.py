@@ -406,3 +406,22 @@ def test_fused_loss_nodes_match_composed_path(ft, dev, reduction, rnnt_type):
     np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
     np.testing.assert_allclose(a[1], b[1], rtol=1e-5)
     assert max_rel(a[2], b[2]) <= 1e-5 and max_rel(a[3], b[3]) <= 1e-5
+
+
+def test_out_of_range_caller_data_does_not_fault(ft, dev):
+    """Malformed boundary rows, symbols and ranges (caller data the reference never validates) must not send a kernel
+    out of bounds: boundaries are clamped into the lattice, symbols into the vocabulary, gather rows into lm; rows of
+    `ranges` outside the lattice receive no gradient.  Only "runs, finite where defined" is asserted."""
+    B, T, S, C, r = 2, 20, 6, 8, 3
+    g = torch.Generator(device="cpu").manual_seed(3)
+    am = torch.randn((B, T, C), generator=g).to(dev).requires_grad_(True)
+    lm = torch.randn((B, S + 1, C), generator=g).to(dev).requires_grad_(True)
+    sym = torch.tensor([[0, 1, 99, -5, 2, 3], [7, 7, 7, 1000000, 0, 1]], dtype=torch.int32, device=dev)
+    bd = torch.tensor([[0, 0, S + 50, T + 70], [-3, -2, S, T]], dtype=torch.int32, device=dev)
+    loss, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, C - 1, bd, reduction="sum", calc_gradients=True)
+    ranges = torch.tensor([-4, 0, 1000], dtype=torch.int32, device=dev).expand(B, T, r).contiguous()
+    am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
+    ploss = ft.rnnt_loss_pruned(torch.tanh(am_p + lm_p), sym, ranges, C - 1, bd, reduction="sum")
+    (loss + ploss).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and torch.isfinite(am.grad).all() and torch.isfinite(lm.grad).all()

@@ -46,8 +46,10 @@ struct Bound { int sb, tb, se, te; };
 __device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ boundary, int b, int S, int T) {
   Bound r;
   if (boundary) {
-    r.sb = boundary[4 * b + 0]; r.tb = boundary[4 * b + 1];
-    r.se = boundary[4 * b + 2]; r.te = boundary[4 * b + 3];
+    // clamped into the lattice: a malformed row then behaves like its intersection with [0,S] x [0,T] instead of
+    // sending a kernel out of bounds (the reference only asserts shapes, mutual_information_cuda.cu:773-785)
+    r.sb = max(boundary[4 * b + 0], 0); r.tb = max(boundary[4 * b + 1], 0);
+    r.se = min(boundary[4 * b + 2], S); r.te = min(boundary[4 * b + 3], T);
   } else { r.sb = 0; r.tb = 0; r.se = S; r.te = T; }
   return r;
 }

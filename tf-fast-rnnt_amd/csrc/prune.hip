@@ -162,7 +162,7 @@ __global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict
         f4 l[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (k0 + u < r) l[u] = reinterpret_cast<const f4u*>(lmb + (size_t)rg[k0 + u] * C)[c4];
+          if (k0 + u < r) l[u] = reinterpret_cast<const f4u*>(lmb + (size_t)min(max(rg[k0 + u], 0), S1 - 1) * C)[c4];   // caller data: kept in bounds
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (k0 + u < r) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict
       const float a = am[bt * C + c];
       for (int k = 0; k < r; ++k) {
         ao[(size_t)k * C + c] = a;
-        lo[(size_t)k * C + c] = lmb[(size_t)rg[k] * C + c];
+        lo[(size_t)k * C + c] = lmb[(size_t)min(max(rg[k], 0), S1 - 1) * C + c];
       }
     }
   }

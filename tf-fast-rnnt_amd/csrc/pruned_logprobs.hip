@@ -128,7 +128,7 @@ __global__ void band_to_lattice_kernel(const float* __restrict__ logits, const i
       const size_t row = bt * r + k;
       const float l = lse[row];
       vy = logits[row * C + blank] - l;                       // :995-996
-      if (s < S) vx = logits[row * C + symbols[(size_t)b * S + s]] - l;   // :961-965
+      if (s < S) vx = logits[row * C + min(max(symbols[(size_t)b * S + s], 0), C - 1)] - l;   // :961-965 (symbol kept in bounds)
     }
   }
   if (t < T) py[((size_t)b * (S + 1) + s) * T + t] = vy;
@@ -164,11 +164,12 @@ __global__ void band_grad_kernel(const float* __restrict__ logits, const int32_t
   const float sc = scale.at(b);
   float gx = 0.0f;
   int sym = blank;
-  if (s < S) {
+  const bool sok = s >= 0 && s <= S;     // ranges are caller data: a row outside the lattice gets no gradient
+  if (sok && s < S) {
     sym = symbols[(size_t)b * S + s];
     if (MOD || t != te) gx = gpx[((size_t)b * S + s) * T1 + t] * sc;   // overwritten cells get no gradient
   }
-  const float gy = gpy[((size_t)b * (S + 1) + s) * T + t] * sc;
+  const float gy = sok ? gpy[((size_t)b * (S + 1) + s) * T + t] * sc : 0.0f;
   const float tot = gx + gy;
   const float l = lse[row];
   const float* x = logits + row * C;

@@ -123,7 +123,7 @@ __global__ void simple_fwd_kernel(const float* __restrict__ am, const float* __r
   float* rs_ulog = rs_lon + (S + 1);
   int* rs_sym = reinterpret_cast<int*>(rs_ulog + (S + 1));
   for (int s = threadIdx.x; s <= S; s += blockDim.x) {
-    const int sym = (s < S) ? symbols[(size_t)b * S + s] : blank;
+    const int sym = (s < S) ? min(max(symbols[(size_t)b * S + s], 0), C - 1) : blank;   // kept in bounds
     rs_sym[s] = sym;
     rs_lmsym[s] = lmb[(size_t)s * C + sym];
     rs_lmblank[s] = lmb[(size_t)s * C + blank];
@@ -247,6 +247,7 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
   const bool tok = t < T;
   const bool xok = tok && (MOD || t != te);
   const int32_t* symb = symbols + (size_t)b * S;
+  auto symc = [&](int si) { return min(max(symb[si], 0), C - 1); };   // caller data kept inside the accumulator tile
   // rows grouped by symbol class: thread row ty owns the columns with sym % 8 == ty (no two threads ever touch the
   // same accumulator, rows are added in ascending s: deterministic).  Each 32-thread row first builds the ordered
   // list of its rows in LDS (ballot compaction), then sweeps only those -- S/8 iterations instead of S.
@@ -257,7 +258,7 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
     constexpr unsigned kRowMask = (TT == 32) ? 0xffffffffu : ((1u << (TT & 31)) - 1u);
     for (int s0 = 0; s0 < S; s0 += TT) {
       const int s = s0 + tx;
-      const bool mine = s < S && (symb[s] & (NY - 1)) == ty;
+      const bool mine = s < S && (symc(s) & (NY - 1)) == ty;
       const unsigned m32 = (unsigned)(__ballot(mine) >> hshift) & kRowMask;
       if (mine) slist[cnt + __popc(m32 & ((1u << tx) - 1u))] = (unsigned short)s;
       cnt += __popc(m32);
@@ -273,15 +274,15 @@ __global__ void simple_bwd_am_kernel(const float* __restrict__ gpx, const float*
       const int s_0 = slist[i], s_1 = slist[i + 1], s_2 = slist[i + 2], s_3 = slist[i + 3];
       const float g0 = gcol[(size_t)s_0 * T1] * sc, g1 = gcol[(size_t)s_1 * T1] * sc;
       const float g2 = gcol[(size_t)s_2 * T1] * sc, g3 = gcol[(size_t)s_3 * T1] * sc;
-      acc[tx * ld + symb[s_0]] += g0; cx += g0;
-      acc[tx * ld + symb[s_1]] += g1; cx += g1;
-      acc[tx * ld + symb[s_2]] += g2; cx += g2;
-      acc[tx * ld + symb[s_3]] += g3; cx += g3;
+      acc[tx * ld + symc(s_0)] += g0; cx += g0;
+      acc[tx * ld + symc(s_1)] += g1; cx += g1;
+      acc[tx * ld + symc(s_2)] += g2; cx += g2;
+      acc[tx * ld + symc(s_3)] += g3; cx += g3;
     }
     for (; i < cnt; ++i) {
       const int s_0 = slist[i];
       const float g0 = gcol[(size_t)s_0 * T1] * sc;
-      acc[tx * ld + symb[s_0]] += g0; cx += g0;
+      acc[tx * ld + symc(s_0)] += g0; cx += g0;
     }
   }
   if (tok) {
