@@ -1,7 +1,8 @@
 // csrc/mi_wave_bidir.hip -- bidirectional ("meet in the middle") wavefront mutual-information kernels for gfx950,
-// the product path.  Same machinery as mi_wave_chain.hip (one 3-wave workgroup per 64-row band, bands chained
-// through 8-byte granules, time-skewed wavefront, log2 domain), but the serial dependency chain -- the one thing
-// that bounds this kernel -- is cut in half:
+// the product path.  Same ideas as mi_wave_chain.hip (one workgroup per 64-row band, bands chained through 8-byte
+// granules, time-skewed wavefront, log2 domain) with a 4-wave workgroup (compute / IO-in / COMM / IO-out: one wave per
+// SIMD of a CU), and the serial dependency chain -- the one thing that bounds this kernel -- is
+// cut in half:
 //
 //   forward launch, 2 * B * NB workgroups
 //     dir 0 "alpha":  p(s,t) from the origin (s_begin,t_begin) up to the CUT, the anti-diagonal
@@ -9,7 +10,7 @@
 //     dir 1 "beta":   q(s,t) = log-prob of reaching (s_end,t_end) from (s,t), from the end cell back to the same cut.
 //                     In reversed coordinates r = s_end - s, c = t_end - t this is the SAME recursion with
 //                     X(r,c) = px[s,t], Y(r,c) = py[s,t]  (reference recursion: mutual_information_cuda.cu:149-239,
-//                     mirrored), so the compute and COMM waves are shared and only the IO wave's addressing differs.
+//                     mirrored), so the compute and COMM waves are shared and only the IO waves' addressing differs.
 //     Both store, per cell, the split ratio G = sigmoid(a - b) of the two incoming terms (alpha: what fraction of
 //     p(s,t) arrived through px; beta: what fraction of q(s,t) leaves through px) in their own lattice, and the
 //     values on the cut in `pmid`.
@@ -116,7 +117,7 @@ __device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
 #define FTR_TP(k) (lds + (6 + ((k) & 1)) * TILE_F4)
 
 // ------------------------------------------------------------------------------------------------- forward
-// One direction of one band.  REVM selects the IO wave's addressing (see the header).
+// One direction of one band.  REVM selects the IO waves' addressing (see the header).
 template <bool MOD, bool REVM>
 __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float* __restrict__ px,
                                                const float* __restrict__ py, const Bound bd, float* __restrict__ wsb,
