@@ -42,6 +42,33 @@ struct Scale {
 };
 inline Scale scale_none() { return Scale{nullptr, 0, 1.0f}; }
 
+// Wave64 reductions on the VALU (DPP row shifts + row broadcasts, result read from lane 63) instead of six LDS
+// round trips (ds_bpermute): the row kernels do two of these per 2-4 KB row.  Every lane gets the result.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_take(float identity, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, src),
+                                                               CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_take<0x111, 0xf, 0xf>(0.0f, v);   // row_shr:1
+  v += dpp_take<0x112, 0xf, 0xf>(0.0f, v);   // row_shr:2
+  v += dpp_take<0x114, 0xf, 0xe>(0.0f, v);   // row_shr:4
+  v += dpp_take<0x118, 0xf, 0xc>(0.0f, v);   // row_shr:8  -> lane 15 of every row holds the row's sum
+  v += dpp_take<0x142, 0xa, 0xf>(0.0f, v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc, 0xf>(0.0f, v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  constexpr float ninf = -__builtin_inff();
+  v = fmaxf(v, dpp_take<0x111, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_take<0x112, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_take<0x114, 0xf, 0xe>(ninf, v));
+  v = fmaxf(v, dpp_take<0x118, 0xf, 0xc>(ninf, v));
+  v = fmaxf(v, dpp_take<0x142, 0xa, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_take<0x143, 0xc, 0xf>(ninf, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 struct Bound { int sb, tb, se, te; };
 __device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ boundary, int b, int S, int T) {
   Bound r;

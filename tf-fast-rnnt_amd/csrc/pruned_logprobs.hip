@@ -11,16 +11,8 @@
 namespace ftr {
 namespace {
 
-__device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 32, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64));  v = fmaxf(v, __shfl_xor(v, 2, 64));  v = fmaxf(v, __shfl_xor(v, 1, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);  v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 1, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // logsumexp of each row, the row held in registers (C % 4 == 0, C <= 256 * NQ): one 16-byte load per lane and quad,
 // all of a wave's loads (RW rows x NQ quads) issued before the first is used, a single pass over the data.

@@ -28,16 +28,8 @@ constexpr int kTTwide = 32;                      // frames per tile for small vo
 constexpr int kTTnarrow = 16;                    // above FTR_TT_NARROW_ABOVE columns: more workgroups per CU (LDS) beats longer
                                                  // row segments (measured at C = 500: fwd 60 -> 47 us, bwd_am 73 -> 65 us; C = 1024: 374 -> 242, 546 -> 420)
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // probs[row, :] = exp(x[row, :] - max(x[row, :])), rowmax[row] = max.  One wave per row.
 template <bool VEC>
