@@ -291,6 +291,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (never set by the driver): several ranks on ONE card over gloo exercise the N > 1 control flow
+    # where no multi-GPU node is at hand
+    if "FTR_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["FTR_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("FTR_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -299,7 +304,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
