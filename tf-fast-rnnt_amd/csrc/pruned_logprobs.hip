@@ -37,35 +37,40 @@ __global__ __launch_bounds__(256) void lse_rows_reg_kernel(const float* __restri
       }
     }
   };
-  size_t row0 = wave * RW;
-  if (row0 >= rows) return;
-  f4 cur[RW][NQ], nxt[RW][NQ];
-  fetch(row0, cur);
-  for (;;) {
-    const size_t rown = row0 + nwaves * RW;
-    const bool more = rown < rows;
-    if (more) fetch(rown, nxt);
+  auto reduce = [&](size_t row0, const f4 (&v)[RW][NQ]) {
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
       float m = -INFINITY;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(cur[w][q][0], cur[w][q][1])), fmaxf(cur[w][q][2], cur[w][q][3]));
+      for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(v[w][q][0], v[w][q][1])), fmaxf(v[w][q][2], v[w][q][3]));
       m = wave_max(m);
       float sum = 0.0f;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel: bit-identical lse
-          sum += __expf(cur[w][q][0] - m) + __expf(cur[w][q][1] - m) + __expf(cur[w][q][2] - m) + __expf(cur[w][q][3] - m);
+        if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel
+          sum += __expf(v[w][q][0] - m) + __expf(v[w][q][1] - m) + __expf(v[w][q][2] - m) + __expf(v[w][q][3] - m);
       }
       sum = wave_sum(sum);
       if (lane == 0 && row0 + w < rows) lse[row0 + w] = m + __logf(sum);
     }
-    if (!more) break;
-#pragma unroll
-    for (int w = 0; w < RW; ++w)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) cur[w][q] = nxt[w][q];
-    row0 = rown;
+  };
+  // two register sets used in turn (no copies): while one is reduced the other one's loads are in flight
+  const size_t stride = nwaves * RW;
+  size_t row0 = wave * RW;
+  if (row0 >= rows) return;
+  f4 bufa[RW][NQ], bufb[RW][NQ];
+  fetch(row0, bufa);
+  for (;;) {
+    const bool more1 = row0 + stride < rows;
+    if (more1) fetch(row0 + stride, bufb);
+    reduce(row0, bufa);
+    if (!more1) break;
+    row0 += stride;
+    const bool more2 = row0 + stride < rows;
+    if (more2) fetch(row0 + stride, bufa);
+    reduce(row0, bufb);
+    if (!more2) break;
+    row0 += stride;
   }
 }
 
