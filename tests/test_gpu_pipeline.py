@@ -425,3 +425,36 @@ def test_out_of_range_caller_data_does_not_fault(ft, dev):
     (loss + ploss).backward()
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and torch.isfinite(am.grad).all() and torch.isfinite(lm.grad).all()
+
+
+@pytest.mark.parametrize("name", ["c1_B2_T8_S4_C16", "seed1234_B2_T10_S7_C4", "seed12345_B2_T200_S50_C50"])
+def test_against_committed_golden_fixtures(ft, dev, name):
+    """The HIP path against the committed fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the
+    oracle; the reference holds no expected values of its own): every stage of the pipeline on the fixture's inputs.
+    Ranges bit-exact given the fixture's occupancies; losses 1e-4 elementwise; lattices and gradients 1e-4 normwise
+    (5e-4 for the T=200 fixture, where float32 log-domain noise of the oracle itself is 3e-4)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    blank = int(g["termination_symbol"])
+    am, lm, sym, bd = (_t(g[k], dev) for k in ("am", "lm", "symbols", "boundary"))
+    tol = 5e-4 if name.startswith("seed12345") else 1e-4
+    px, py = ft.get_rnnt_logprobs(lm, am, sym, blank, "regular", bd)
+    assert np.array_equal(np.isneginf(px.cpu().numpy()), np.isneginf(g["simple_px"]))
+    assert max_rel(px.cpu().numpy(), g["simple_px"]) <= 1e-5 and max_rel(py.cpu().numpy(), g["simple_py"]) <= 1e-5
+    loss, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, reduction="none", calc_gradients=True)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["simple_loss"], rtol=1e-4)
+    assert max_rel(gx.cpu().numpy(), g["simple_px_grad"]) <= tol and max_rel(gy.cpu().numpy(), g["simple_py_grad"]) <= tol
+    sl, (sgx, sgy) = ft.rnnt_loss_smoothed(lm, am, sym, blank, lm_only_scale=0.1, am_only_scale=0.2, boundary=bd,
+                                           reduction="none", delay_penalty=0.2, calc_gradients=True)
+    np.testing.assert_allclose(sl.cpu().numpy(), g["smoothed_loss"], rtol=1e-4)
+    assert max_rel(sgx.cpu().numpy(), g["smoothed_px_grad"]) <= tol and max_rel(sgy.cpu().numpy(), g["smoothed_py_grad"]) <= tol
+    for r in [int(v) for v in g["s_ranges"]]:
+        want = g[f"ranges_r{r}"]
+        got = ft.get_rnnt_prune_ranges(_t(g["smoothed_px_grad"], dev), _t(g["smoothed_py_grad"], dev), bd, r)
+        assert np.array_equal(got.cpu().numpy(), want)                      # integer output: bit-exact
+        am_p, lm_p = ft.do_rnnt_pruning(am, lm, _t(want, dev))
+        logits = torch.sigmoid(am_p + lm_p).detach().requires_grad_(True)
+        pl = ft.rnnt_loss_pruned(logits, sym, _t(want, dev), blank, bd, delay_penalty=0.2, reduction="mean")
+        pl.backward()
+        np.testing.assert_allclose(pl.item(), float(g[f"pruned_loss_r{r}"]), rtol=1e-4)
+        assert max_rel(logits.grad.cpu().numpy(), g[f"pruned_logits_grad_r{r}"]) <= tol
