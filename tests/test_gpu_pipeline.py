@@ -196,6 +196,27 @@ def test_full_size_pruned_step_properties(ft, dev):
     np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=1e-5)
 
 
+def test_full_size_smoothed_pruned_step_properties(ft, dev):
+    """BASELINE config c4's per-GPU share (B=32, T=2000, S=300, C=1024, s_range=5) with the smoothed first pass, ragged
+    boundaries: the same size-independent properties as above (ranges monotone with steps <= s_range-1, occupancies sum
+    to 1 per valid frame, softmax-gradient rows sum to 0), plus finite gradients w.r.t. am and lm."""
+    from bench import make_inputs, pruned_step
+    inp = make_inputs(B=32, T=2000, S=300, C=1024, seed=1, device=dev, ragged=True)
+    out = pruned_step(inp, s_range=5, keep=True, first_pass="smoothed")
+    torch.cuda.synchronize()
+    s0 = out["ranges"].cpu().numpy()[:, :, 0]
+    assert (np.diff(s0, axis=1) >= 0).all() and (np.diff(s0, axis=1) <= 4).all() and (s0 >= 0).all() and (s0 <= 300 - 5 + 1).all()
+    bd = inp["boundary"].cpu().numpy()
+    pyg = out["py_grad"].sum(dim=1).cpu().numpy()
+    for b in range(32):
+        np.testing.assert_allclose(pyg[b, :bd[b, 3]], 1.0, rtol=2e-4)
+        assert not pyg[b, bd[b, 3]:].any()
+    g = out["logits_grad"]
+    assert torch.isfinite(g).all() and torch.isfinite(out["pruned_loss"]).all() and torch.isfinite(out["simple_loss"]).all()
+    np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=2e-5)
+    assert torch.isfinite(out["am_grad"]).all() and torch.isfinite(out["lm_grad"]).all()
+
+
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
 @pytest.mark.parametrize("cfg", [(3, 24, 8, 12), (2, 70, 33, 50), (2, 33, 5, 7), (2, 37, 9, 700), (1, 21, 4, 641)])
 def test_native_simple_builder_forward_backward(ft, dev, oracle, rnnt_type, cfg):
