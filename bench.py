@@ -205,10 +205,11 @@ def algorithmic_bytes(B, T, S, C, r):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(B, T, S, C, r, sample_B=8, seed=0, min_seconds=12.0):
-    """The oracle (CPU port of the same path) timed on this host, 1 thread, on batches of `sample_B`
-    utterances of the same workload repeated until >= `min_seconds` of CPU work: px/py builder + recursion
-    fwd+bwd + ranges + gather + sigmoid + pruned log-probs + recursion fwd+bwd + gradient w.r.t. logits."""
+def _cpu_pipeline_worker(job):
+    """One worker of the CPU baseline: the oracle's whole loss pipeline on batches of `sample_B` utterances of the
+    workload, single-threaded, repeated until `seconds` have passed.  Returns (utterances done, seconds)."""
+    B, T, S, C, r, sample_B, seed, seconds = job
+    os.environ["OMP_NUM_THREADS"] = "1"
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rnnt_oracle as O
     try:
@@ -222,7 +223,6 @@ def cpu_baseline(B, T, S, C, r, sample_B=8, seed=0, min_seconds=12.0):
     lm = rng.standard_normal((sample_B, S + 1, C)).astype(np.float32)
     sym = rng.integers(0, C - 1, (sample_B, S)).astype(np.int32)
     bd = np.zeros((sample_B, 4), np.int32); bd[:, 2] = S; bd[:, 3] = T
-    os.environ["OMP_NUM_THREADS"] = "1"
     done = 0
     with limiter:
         t0 = time.perf_counter()
@@ -234,12 +234,56 @@ def cpu_baseline(B, T, S, C, r, sample_B=8, seed=0, min_seconds=12.0):
             O.rnnt_loss_pruned_grad(logits, sym, ranges, C - 1, bd, reduction="sum")
             done += sample_B
             dt = time.perf_counter() - t0
-            if dt >= min_seconds or done >= 4096:
+            if dt >= seconds or done >= 4096:
                 break
-    return dict(value=round(done / dt, 3), unit="utterances/s", cores=1, kind="port",
-                sample=f"{done} utterances of the same workload in batches of {sample_B} (oracle/: C recursion + numpy "
-                       f"builders, single thread, {dt:.1f} s of CPU work; loss pipeline forward + gradients w.r.t. "
-                       f"px/py and pruned logits, without the autograd tail to am/lm)")
+    return done, dt
+
+
+def _host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return dict(nproc=os.cpu_count(), usable_cores=usable, cpu_model=model)
+
+
+def cpu_baseline(B, T, S, C, r, sample_B=4, seed=0, seconds=9.0, max_workers=16):
+    """SURVEY.md 8(d) CPU baseline: the oracle (CPU port of the same path: px/py builder + recursion fwd+bwd + ranges +
+    gather + sigmoid + pruned log-probs + recursion fwd+bwd + gradient w.r.t. logits) timed on this host, (i) on one
+    thread and (ii) on all usable cores, parallel over the batch dimension (one single-threaded worker process per
+    core, each on its own utterances).  `value` is the all-cores rate; the single-thread rate is reported beside it."""
+    import multiprocessing as mp
+    host = _host_description()
+    one_done, one_dt = _cpu_pipeline_worker((B, T, S, C, r, sample_B, seed, seconds))
+    single = one_done / one_dt
+    workers = max(1, min(host["usable_cores"], max_workers))
+    multi = None
+    if workers > 1:
+        ctx = mp.get_context("spawn")     # fresh interpreters: the parent holds a HIP context
+        with ctx.Pool(workers) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_pipeline_worker, [(B, T, S, C, r, sample_B, seed + 1 + i, seconds) for i in range(workers)])
+            wall = time.perf_counter() - t0
+        # every worker runs for >= `seconds` after its own start-up; rate = sum of the workers' own rates
+        multi = sum(d / t for d, t in res)
+        multi_done = sum(d for d, _ in res)
+    value = multi if multi is not None else single
+    return dict(value=round(value, 3), unit="utterances/s", cores=workers, kind="port",
+                single_thread_value=round(single, 3), host=host,
+                sample=f"the oracle's whole loss pipeline (oracle/: C recursion + numpy builders; forward + gradients w.r.t. "
+                       f"px/py and pruned logits, without the autograd tail to am/lm) on batches of {sample_B} utterances of "
+                       f"the same workload: 1 thread {one_done} utterances in {one_dt:.1f} s; "
+                       + (f"{workers} single-threaded worker processes, {multi_done} utterances, {wall:.1f} s wall incl. start-up"
+                          if multi is not None else "one usable core only"))
 
 
 # ------------------------------------------------------------------------------------------------ hipGraph replay
@@ -272,6 +316,38 @@ def graph_replay(step_fn, steps):
         return dict(ms_per_step=None, error=f"{type(e).__name__}: {e}"[:300])
 
 
+# ------------------------------------------------------------------------------------------------ self-launch
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh children, one device each, RCCL),
+    rank 0 prints the JSON line.  The parent never touches the GPU (torch.cuda.device_count() does not initialise it
+    on this image) and never re-execs itself.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    forced = "FTR_BENCH_FORCE_DEVICE" in os.environ      # rehearsal: every rank on one card (gloo backend)
+    have = torch.cuda.device_count()
+    if not forced and have < n:
+        print(f"bench.py: --gpus {n} asked for but only {have} HIP device(s) are visible; not measuring fewer GPUs "
+              f"under an n_gpus={n} label", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        print(f"bench.py: a rank exited with code {rc}", file=sys.stderr)
+    return rc
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -288,8 +364,13 @@ def main():
                     help="occupancy pass; default simple, smoothed for c4 (BASELINE.json configs[3])")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))      # before this process makes any GPU call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         f"refusing to print a line whose n_gpus would not be what was asked for")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs (never set by the driver): several ranks on ONE card over gloo exercise the N > 1 control flow
     # where no multi-GPU node is at hand
@@ -305,8 +386,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     import tf_fast_rnnt as ft
     B, T, S, C, r = CONFIGS[args.config]
@@ -363,20 +442,27 @@ def main():
         kernels[name] = dict(avg_us=round(rec["avg_us"], 2), calls_per_step=per_step_calls,
                              algorithmic_MB=round(alg[name] / 1e6, 1) if name in alg else None,
                              GBps=round(alg[name] / (rec["avg_us"] * 1e-6) / 1e9, 1) if name in alg else None)
-    # dominant native call of the step = largest total time
-    native_calls = [n for n in calls if n.startswith("ftr_")]
-    dom = max(native_calls, key=lambda n: calls[n]["total_ms"]) if native_calls else None
+    # roofline: always the kernel pair north_star names, the mutual-information recursion forward + backward (SURVEY.md
+    # 8(d): 32 bytes per lattice cell for the pair), whatever else is slow in the step -- so that the line is comparable
+    # from run to run; every other native call is in `kernels`.  avg_launch_us = the HIP-event time of the two calls
+    # (each call = its kernels back to back on the stream; the rocprofv3 --kernel-trace --stats summary of this same
+    # command under profiles/ gives the per-kernel split).
+    pair = ("ftr_mutual_information_fwd_f32", "ftr_mutual_information_bwd_f32")
     roofline = None
     traffic, traffic_file = pmc_traffic(args.config) if (first_pass == "simple" and not args.ragged) else (None, None)
     if traffic:
         for name in kernels:
             kernels[name]["pmc_hbm_MB"] = round(traffic[name] / 1e6, 1) if name in traffic else None
-    if dom is not None and dom in alg:
-        achieved = alg[dom] / (calls[dom]["avg_us"] * 1e-6) / 1e9
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    if all(n in calls for n in pair):
+        pair_us = sum(calls[n]["avg_us"] for n in pair)
+        pair_bytes = sum(alg[n] for n in pair)
+        achieved = pair_bytes / (pair_us * 1e-6) / 1e9
+        roofline = dict(bound="hbm", kernel="+".join(pair), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=(traffic or {}).get(dom), traffic_source=traffic_file,
-                        avg_launch_us=round(calls[dom]["avg_us"], 2), algorithmic_bytes=alg[dom])
+                        traffic=(sum(traffic[n] for n in pair) if traffic and all(n in traffic for n in pair) else None),
+                        traffic_source=traffic_file, avg_launch_us=round(pair_us, 2),
+                        avg_launch_us_each={n: round(calls[n]["avg_us"], 2) for n in pair},
+                        algorithmic_bytes=pair_bytes, launches_per_step=calls[pair[0]]["calls"] / len(sampled))
     # the streaming share of the step against the same roofline: all native calls together
     tot_alg = sum(alg[n] * calls[n]["calls"] for n in calls if n in alg) / len(sampled)
     tot_us = sum(calls[n]["total_ms"] for n in calls if n in alg) * 1e3 / len(sampled)

@@ -1,9 +1,11 @@
-# slot-time experiments: which wave bounds the bidirectional forward kernel (results are wrong by construction)
+# slot-time experiments: which wave bounds the bidirectional kernels (results of the variants are wrong by construction)
+# usage: bash scripts/mi_exp.sh VARIANT...   (libraries gpurun_exp/libftr_<VARIANT>.so, "product" = the in-tree library)
 mkdir -p gpurun_out
-for v in "" NODRAIN NOCOMPUTE NOPOLL; do
-  if [ -z "$v" ]; then unset FTR_LIB_PATH; else export FTR_LIB_PATH=$PWD/gpurun_exp/libftr_$v.so; fi
-  echo "== variant ${v:-product}"
-  timeout -k 10 120 python scripts/mi_bench.py 32 200 1000 2>&1 | grep "warm" | head -1
-  timeout -k 10 120 python scripts/mi_bench.py 32 63 1000 2>&1 | grep "warm" | head -1
+for v in "$@"; do
+  if [ "$v" = product ]; then unset FTR_LIB_PATH; else export FTR_LIB_PATH=$PWD/gpurun_exp/libftr_$v.so; fi
+  echo "== variant $v"
+  for shape in "32 200 1000" "32 63 1000" "8 1000 8000"; do
+    timeout -k 10 120 python scripts/mi_bench.py $shape 2>&1 | grep "warm" | head -1
+  done
 done > gpurun_out/mi_exp.log 2>&1
 cat gpurun_out/mi_exp.log

@@ -16,7 +16,7 @@ from helpers import assert_parity, max_rel, random_lattice
 
 pytestmark = pytest.mark.gpu
 
-IMPLS = {"wavefront": 0, "plain": 1, "mono": 2, "duo": 3, "chain": 4}
+IMPLS = {"wavefront": 0, "plain": 1}
 
 
 def _run(ft, dev, px, py, bd, impl, need_grads=True):
@@ -40,14 +40,14 @@ def test_selftest(ft, dev):
     assert int(scratch[0].item()) == 1
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono", "duo", "chain"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
 @pytest.mark.parametrize("modified", [False, True])
 @pytest.mark.parametrize("shape", [(2, 0, 5), (2, 5, 1), (1, 0, 1), (2, 1, 40), (2, 4, 8), (3, 1, 1), (3, 7, 10), (4, 50, 200), (2, 63, 70), (2, 64, 65),
                                    (2, 65, 33), (3, 130, 90), (2, 200, 257), (1, 300, 40), (2, 383, 150), (2, 400, 130), (1, 1100, 70)])
 def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
     B, S, T = shape
-    if (impl == "duo" and S + 1 > 384) or (impl in ("mono", "plain") and S + 1 > 1024):
-        pytest.skip("family does not cover this many rows")
+    if impl == "plain" and S + 1 > 1024:
+        pytest.skip("the plain family (one thread per row, one workgroup) does not cover this many rows")
     px, py, bd = random_lattice(100 + S + T, B, S, T, modified=modified, ragged=True)
     ans, gx, gy, chk = _run(ft, dev, px, py, bd, impl)
     o_ans, o_p = oracle.mi_forward(px, py, bd)
@@ -73,7 +73,7 @@ def test_mi_parity_f32_oracle(ft, dev, oracle, impl, modified, shape):
         assert not gx[b, :, te + 1:].any() and not gy[b, :, te:].any()
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono", "chain"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
 @pytest.mark.parametrize("modified", [False, True])
 def test_mi_begin_offsets_and_empty(ft, dev, oracle, impl, modified):
     B, S, T = 5, 20, 37
@@ -89,7 +89,7 @@ def test_mi_begin_offsets_and_empty(ft, dev, oracle, impl, modified):
     assert max_rel(gx[ok], o_gx[ok]) <= 1e-4 and max_rel(gy[ok], o_gy[ok]) <= 1e-4
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
 @pytest.mark.parametrize("modified", [False, True])
 @pytest.mark.parametrize("frac", [0.02, 0.3])
 def test_mi_neg_inf_entries(ft, dev, oracle, impl, modified, frac):
@@ -116,7 +116,7 @@ def test_mi_boundary_none(ft, dev, oracle):
     assert max_rel(gx, o_gx) <= 1e-4 and max_rel(gy, o_gy) <= 1e-4
 
 
-@pytest.mark.parametrize("impl", ["wavefront", "plain", "mono"])
+@pytest.mark.parametrize("impl", ["wavefront", "plain"])
 def test_mi_vs_float64_oracle_long(ft, dev, oracle, impl):
     """Long lattice with realistic magnitudes (px,py ~ log(1/C)): compare with the float64 oracle and
     require the native result to be no worse than the float32 reference arithmetic."""
@@ -164,7 +164,7 @@ def test_mi_full_size_properties(ft, dev):
     bd[1, 2] = 77; bd[1, 3] = 513; bd[2, 2] = 199; bd[2, 3] = 999
     px = px.scatter(2, bd[:, 3].long().reshape(B, 1, 1).expand(B, S, 1), float("-inf"))
     outs = {}
-    for impl in ("wavefront", "plain", "mono", "duo", "chain"):
+    for impl in ("wavefront", "plain"):
         outs[impl] = _run(ft, dev, px.numpy(), py.numpy(), bd.numpy(), impl)
     for impl, (ans, gx, gy, chk) in outs.items():
         tol = 1e-2 if impl == "plain" else 1e-4     # plain = reference arithmetic: its normalisation drifts (3e-3 here)
@@ -174,13 +174,6 @@ def test_mi_full_size_properties(ft, dev):
             np.testing.assert_allclose(gx[b, :se, :te + 1].sum(axis=1), 1.0, rtol=tol)
         np.testing.assert_allclose(chk, 1.0, rtol=tol)
     np.testing.assert_allclose(outs["wavefront"][0], outs["plain"][0], rtol=1e-5)
-    for other in ("mono", "duo"):   # same arithmetic as chain, different work distribution
-        np.testing.assert_allclose(outs["chain"][0], outs[other][0], rtol=1e-6)
-        assert max_rel(outs["chain"][1], outs[other][1]) <= 1e-5 and max_rel(outs["chain"][2], outs[other][2]) <= 1e-5
-    # the bidirectional kernels reach the same quantities along different (half as long) chains: ans = logsumexp of
-    # p + q over the cut instead of p at the end cell.  Two float32 evaluations at T + S = 1200: 1e-5 / 2e-3.
-    np.testing.assert_allclose(outs["wavefront"][0], outs["chain"][0], rtol=1e-5)
-    assert max_rel(outs["wavefront"][1], outs["chain"][1]) <= 2e-3 and max_rel(outs["wavefront"][2], outs["chain"][2]) <= 2e-3
     # plain = the reference arithmetic, whose float32 noise at this size is ~7e-3
     assert max_rel(outs["wavefront"][1], outs["plain"][1]) <= 2e-2
     assert max_rel(outs["wavefront"][2], outs["plain"][2]) <= 2e-2

@@ -222,7 +222,7 @@ def test_full_size_smoothed_pruned_step_properties(ft, dev):
 def test_native_simple_builder_forward_backward(ft, dev, oracle, rnnt_type, cfg):
     """get_rnnt_logprobs (native prologue/epilogue kernels around the GEMM): px/py against the oracle with the exact
     -inf pattern; d/d am and d/d lm against float64 autograd through the op-by-op torch restatement."""
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_torch
+    from torch_restatements import get_rnnt_logprobs_torch as _get_rnnt_logprobs_torch
     B, T, S, C = cfg
     d = synthetic(11, B, T, S, C, ragged=True)
     am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
@@ -265,7 +265,7 @@ def test_native_smoothed_builder_forward_backward(ft, dev, oracle, rnnt_type, sc
     """get_rnnt_logprobs_smoothed on the native builder kernels (rnnt_loss.py:1132-1367): px/py against the oracle
     with the exact -inf pattern (tolerance 2e-5 absolute/relative: f32 sums in a different order); d/d am and d/d lm
     against float64 autograd through the op-by-op torch restatement, 1e-4 normwise."""
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_smoothed_torch
+    from torch_restatements import get_rnnt_logprobs_smoothed_torch as _get_rnnt_logprobs_smoothed_torch
     B, T, S, C = cfg
     d = synthetic(21, B, T, S, C, ragged=True)
     am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
@@ -308,7 +308,7 @@ def test_smoothed_loss_against_oracle(ft, dev, oracle):
 def test_native_joint_builder_and_unpruned_loss(ft, dev, oracle, rnnt_type):
     """get_rnnt_logprobs_joint / rnnt_loss (rnnt_loss.py:340-551) on the pruned builder's kernels with identity ranges:
     px/py against the oracle, loss against the oracle, d/d logits against float64 autograd of the torch restatement."""
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_joint_torch
+    from torch_restatements import get_rnnt_logprobs_joint_torch as _get_rnnt_logprobs_joint_torch
     d = synthetic(31, 2, 21, 6, 9, ragged=True)
     logits_np = (d["am"][:, :, None, :] + d["lm"][:, None, :, :]).astype(np.float32)
     logits = _t(logits_np, dev).requires_grad_(True)

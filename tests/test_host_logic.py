@@ -19,7 +19,7 @@ def _t(a):
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
 def test_get_rnnt_logprobs_torch_restatement(ft, oracle, rnnt_type):
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_torch
+    from torch_restatements import get_rnnt_logprobs_torch as _get_rnnt_logprobs_torch
     d = synthetic(0, 3, 11, 6, 9, ragged=True)
     px, py = _get_rnnt_logprobs_torch(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"], rnnt_type, _t(d["boundary"]))
     o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], d["termination_symbol"], rnnt_type, d["boundary"])
@@ -33,7 +33,7 @@ def test_get_rnnt_logprobs_torch_restatement(ft, oracle, rnnt_type):
 @pytest.mark.parametrize("scales", [(0.1, 0.2), (0.0, 0.0), (0.25, 0.0)])
 def test_get_rnnt_logprobs_smoothed(ft, oracle, rnnt_type, scales):
     d = reference_test_recipe(1234, 2, 10, 7, 4)
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_smoothed_torch   # host restatement (autograd oracle on GPU)
+    from torch_restatements import get_rnnt_logprobs_smoothed_torch as _get_rnnt_logprobs_smoothed_torch   # host restatement (autograd oracle on GPU)
     px, py = _get_rnnt_logprobs_smoothed_torch(_t(d["lm"]), _t(d["am"]), _t(d["symbols"]), d["termination_symbol"],
                                                scales[0], scales[1], _t(d["boundary"]), rnnt_type)
     o_px, o_py = oracle.get_rnnt_logprobs_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"],
@@ -45,7 +45,7 @@ def test_get_rnnt_logprobs_smoothed(ft, oracle, rnnt_type, scales):
 
 
 def test_get_rnnt_logprobs_joint(ft, oracle):
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_joint_torch as _joint_torch   # host restatement
+    from torch_restatements import get_rnnt_logprobs_joint_torch as _joint_torch   # host restatement
     d = synthetic(1, 2, 7, 4, 6, ragged=True)
     logits = (d["am"][:, :, None, :] + d["lm"][:, None, :, :]).astype(np.float32)
     for rnnt_type in ("regular", "modified", "constrained"):
@@ -58,7 +58,8 @@ def test_get_rnnt_logprobs_joint(ft, oracle):
 
 
 def test_fix_for_boundary_and_penalty(ft, oracle):
-    from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty, _reduce, _roll_by_shifts, fix_for_boundary
+    from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty, _reduce, fix_for_boundary
+    from torch_restatements import roll_by_shifts as _roll_by_shifts
     rng = np.random.default_rng(0)
     px = rng.standard_normal((3, 4, 9)).astype(np.float32)
     bd = np.array([[0, 0, 4, 8], [0, 0, 2, 5], [0, 0, 4, 1]], dtype=np.int32)
@@ -104,7 +105,7 @@ def _gloo_worker(rank, world, port, B, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tf_fast_rnnt.distributed import all_reduce_sum_differentiable, reduce_loss, shard_batch
-    from tf_fast_rnnt.rnnt_loss import _get_rnnt_logprobs_smoothed_torch as get_rnnt_logprobs_smoothed
+    from torch_restatements import get_rnnt_logprobs_smoothed_torch as get_rnnt_logprobs_smoothed
     torch.manual_seed(0)
     full = torch.randn(B, dtype=torch.float64)            # per-utterance losses of the whole batch
     lo, hi = shard_batch(B, rank, world)
@@ -130,8 +131,20 @@ def _gloo_worker(rank, world, port, B, q):
     px_f, py_f = get_rnnt_logprobs_smoothed(lm, am, sym, C - 1, 0.1, 0.2, None, "regular")
     ok_smoothed = torch.allclose(py_s, py_f[l2:h2], rtol=1e-5, atol=1e-6) and \
         torch.allclose(px_s[:, :, :T], px_f[l2:h2, :, :T], rtol=1e-5, atol=1e-6)
+    # DistributedDataParallel averages gradients: with grad_averaging=True the averaged gradient of the sharded loss is
+    # the single-process gradient of the full-batch mean
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(4, 1).double()
+    xs = torch.randn((B, 4), dtype=torch.float64, generator=torch.Generator().manual_seed(9))
+    ref = torch.nn.Linear(4, 1).double(); ref.load_state_dict(lin.state_dict())
+    (ref(xs).squeeze(1) ** 2).mean().backward()
+    ddp = torch.nn.parallel.DistributedDataParallel(lin)
+    v_ddp = reduce_loss(ddp(xs[lo:hi]).squeeze(1) ** 2, "mean", grad_averaging=True)
+    v_ddp.backward()
+    ok_ddp = torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-10) and torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-10) \
+        and abs(v_ddp.item() - (ref(xs).squeeze(1) ** 2).mean().item()) < 1e-12
     q.put((rank, out["mean"][0], out["sum"][0], out["mean"][1].tolist(), y.detach().tolist(), x.grad.tolist(),
-           full.mean().item(), full.sum().item(), bool(ok_smoothed)))
+           full.mean().item(), full.sum().item(), bool(ok_smoothed), bool(ok_ddp)))
     dist.destroy_process_group()
 
 
@@ -148,10 +161,11 @@ def test_sharded_loss_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, mean_v, sum_v, mean_grad, y, xg, full_mean, full_sum, ok_smoothed in res:
+    for rank, mean_v, sum_v, mean_grad, y, xg, full_mean, full_sum, ok_smoothed, ok_ddp in res:
         np.testing.assert_allclose(mean_v, full_mean, rtol=1e-12)
         np.testing.assert_allclose(sum_v, full_sum, rtol=1e-12)
         np.testing.assert_allclose(mean_grad, 1.0 / B, rtol=1e-12)      # d mean / d loss_b = 1/B on every shard
         assert y == [3.0, 3.0, 3.0]
         assert xg == [2.0, 4.0, 6.0]
+        assert ok_ddp, "DDP-averaged gradient of reduce_loss(grad_averaging=True) != single-process gradient"
         assert ok_smoothed

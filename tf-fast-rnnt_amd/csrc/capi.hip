@@ -23,7 +23,7 @@ int device_ok() {
 int mi_impl() {
   if (g_mi_impl < 0) {
     const char* e = getenv("FTR_MI_IMPL");
-    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : (e && strcmp(e, "mono") == 0) ? 2 : (e && strcmp(e, "duo") == 0) ? 3 : (e && strcmp(e, "chain") == 0) ? 4 : 0;
+    g_mi_impl = (e && strcmp(e, "plain") == 0) ? 1 : 0;
   }
   return g_mi_impl;
 }
@@ -56,18 +56,16 @@ const char* ftr_last_error(void) { return g_err; }
 
 int ftr_set_mi_impl(int impl) {
   const int prev = mi_impl();
-  g_mi_impl = (impl >= 1 && impl <= 4) ? impl : 0;
+  g_mi_impl = (impl == 1) ? 1 : 0;
   return prev;
 }
 int ftr_get_mi_impl(void) { return mi_impl(); }
 
 size_t ftr_mutual_information_workspace_floats(int B, int S, int T) {
   if (B < 0 || S < 0 || T < 0) return 0;
-  // the bidirectional wavefront kernels need the most: two ratio lattices, the cut vectors and two granule regions
-  // (mi_wave_bidir.hip); every other family fits in the same buffer
-  const size_t chain = (size_t)B * (size_t)(S + 1) * (size_t)(T + 1) + mi_chain_extra_floats(B, S, T);
-  const size_t bidir = mi_bidir_workspace_floats(B, S, T);
-  return bidir > chain ? bidir : chain;
+  // the bidirectional wavefront kernels: two ratio lattices, the cut vectors and the hand-off region
+  // (mi_wave_bidir.hip); the plain family's p lattice fits in the same buffer
+  return mi_bidir_workspace_floats(B, S, T);
 }
 
 int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary, float* p,
@@ -81,9 +79,7 @@ int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (mi_impl() == 1) return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
-  if (mi_impl() == 0) return mi_bidir_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
-  if (mi_impl() == 4) return mi_chain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
-  return mi_wave_fwd(px, py, boundary, p, ans, B, S, T, modified, mi_impl() == 2, st);
+  return mi_bidir_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
 }
 
 int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32_t* boundary,
@@ -103,9 +99,7 @@ int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32
     FTR_REQUIRE((px || S == 0) && py, "mutual_information_bwd: the plain family needs px and py");
     return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
   }
-  if (mi_impl() == 0) return mi_bidir_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
-  if (mi_impl() == 4) return mi_chain_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
-  return mi_wave_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, mi_impl() == 2, st);
+  return mi_bidir_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
 }
 
 int ftr_cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, void* stream) {

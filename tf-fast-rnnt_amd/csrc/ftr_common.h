@@ -87,11 +87,6 @@ __device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ bound
 namespace ftr {
 int mi_plain_fwd(const float* px, const float* py, const int32_t* boundary, float* p, float* ans, int B, int S, int T, int modified, hipStream_t st);
 int mi_plain_bwd(const float* px, const float* py, const int32_t* boundary, const float* p, float* p_grad, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
-int mi_wave_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, int force_mono, hipStream_t st);
-int mi_wave_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, int force_mono, hipStream_t st);
-int mi_chain_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
-int mi_chain_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
-size_t mi_chain_extra_floats(int B, int S, int T);
 int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S, int T, int modified, hipStream_t st);
 int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
 size_t mi_bidir_workspace_floats(int B, int S, int T);

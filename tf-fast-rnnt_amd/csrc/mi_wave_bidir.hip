@@ -1,6 +1,6 @@
 // csrc/mi_wave_bidir.hip -- bidirectional ("meet in the middle") wavefront mutual-information kernels for gfx950,
-// the product path.  Same ideas as mi_wave_chain.hip (one workgroup per 64-row band, bands chained through 8-byte
-// granules, time-skewed wavefront, log2 domain) with a 4-wave workgroup (compute / IO-in / COMM / IO-out: one wave per
+// the product path.  One workgroup per 64-row band, bands chained through 8-byte granules, time-skewed wavefront,
+// log2 domain, a 4-wave workgroup (compute / IO-in / COMM / IO-out: one wave per
 // SIMD of a CU), and the serial dependency chain -- the one thing that bounds this kernel -- is
 // cut in half:
 //
@@ -79,7 +79,7 @@ __host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
   return (L + 3) & ~(size_t)3;
 }
 
-// COMM wave helpers (see mi_wave_chain.hip) -----------------------------------------------------------------
+// COMM wave helpers -----------------------------------------------------------------
 __device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
   return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -681,6 +681,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
+#ifndef FTR_EXP_FLOW_NOCOMPUTE
       if (kc >= kfirst && kc < nchunks) {
         if (kc == kfirst) {
           ecarry = in_ring[(CH * kfirst - 1) & (RINGN - 1)];
@@ -689,6 +690,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           compute_chunk(kc, std::false_type{});
         }
       }
+#endif
       FTR_FSYNC();
     }
     FTR_FREPORT(0);
@@ -825,6 +827,9 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     xvalid[m] = r >= 1 && r < Sn;
   }
   auto load_fast = [&](int k, f4 (&gq)[4]) {
+#ifdef FTR_EXP_FLOW_NOLOAD
+    return;
+#endif
     const float* ws_k = REVM ? wsb - CH * k : wsb + CH * k;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -844,6 +849,9 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       if (DOY) gy[m] = sY[fq * PLANE + 16 * m + frow];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all LDS reads in flight together, see the forward body
+#ifdef FTR_EXP_FLOW_NOSTORE
+    if ((DOX ? gx[0][0] : gy[0][0]) != 12345.678f) return;
+#endif
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (DOX && xvalid[m]) *reinterpret_cast<f4u*>(px_k + offPX[m]) = REVM ? rev4(gx[m]) : gx[m];
@@ -1066,6 +1074,26 @@ inline BidirLayout bidir_layout(int B, int S, int T, int modified) {
   return l;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hardware self-test: the wavefront kernels rely on (1) wave_shr:1 DPP shifting across all 64 lanes
+// with lane 0 keeping `old`, (2) 16-byte global loads/stores at 4-byte alignment.  result[0] = 1 if
+// both behave as assumed.
+__global__ void selftest_kernel(const float* __restrict__ in, float* __restrict__ out, int* __restrict__ result) {
+  const int lane = threadIdx.x;
+  const float mine = (float)(lane + 1);
+  const float got = dpp_wave_shr1(-7.0f, mine);
+  const bool ok1 = (lane == 0) ? (got == -7.0f) : (got == (float)lane);
+  const float got0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0x138, 0xf, 0xf, true));
+  const bool ok3 = (lane == 0) ? (got0 == 0.0f) : (got0 == (float)lane);   // bound_ctrl form: lane 0 reads 0
+  // unaligned 16B load at element offset 1 + 5*lane, store at 3 + 5*lane
+  const f4 v = *reinterpret_cast<const f4u*>(in + 1 + 5 * lane);
+  bool ok2 = true;
+  for (int e = 0; e < 4; ++e) ok2 = ok2 && (v[e] == (float)(1 + 5 * lane + e));
+  *reinterpret_cast<f4u*>(out + 3 + 5 * lane) = v;
+  const unsigned long long m = __ballot(ok1 && ok2 && ok3);
+  if (lane == 0) result[0] = (m == ~0ull) ? 1 : 0;
+}
+
 }  // namespace
 
 // floats of workspace the bidirectional kernels need in total (sized for the regular variant, which needs more)
@@ -1115,6 +1143,22 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float
   if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
   else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
+}
+
+int selftest(hipStream_t st, int* result_dev) {
+  // scratch lives behind result_dev: [0] result int, then 512 floats in, 512 floats out
+  float* in = reinterpret_cast<float*>(result_dev + 4);
+  float* out = in + 512;
+  float host[512];
+  for (int i = 0; i < 512; ++i) host[i] = (float)i;
+  if (hipMemcpyAsync(in, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) {
+    set_error("selftest: memcpy failed"); return FTR_ERR_LAUNCH;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) {  // host[] is on the stack
+    set_error("selftest: sync failed"); return FTR_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, in, out, result_dev);
+  return check_launch("selftest");
 }
 
 // diagnostic (make STAMPS=1): see FTR_SYNC above

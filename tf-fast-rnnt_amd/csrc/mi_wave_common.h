@@ -1,4 +1,4 @@
-// csrc/mi_wave_common.h -- constants and helpers shared by the wavefront kernels (mono and duo variants).
+// csrc/mi_wave_common.h -- constants and helpers of the wavefront kernels (mi_wave_bidir.hip).
 #pragma once
 #include "ftr_common.h"
 
@@ -9,15 +9,12 @@ constexpr int CH = 16;              // steps per chunk
 constexpr int NQ = CH / 4;          // quads (4 consecutive steps) per chunk
 constexpr int PLANE = 66;           // float4 per [quad] plane: 64 rows + 2 pad (conflict-free fill+read)
 constexpr int TILE_F4 = NQ * PLANE; // one tile = 264 float4 = 4224 B
-// chunks in flight in registers (prefetch distance): 3 where the register budget allows (<= 8 waves per
-// workgroup), 2 for 16-wave workgroups (128 VGPRs per lane, and 4 waves per SIMD hide latency themselves)
-template <int MAXW> struct Prefetch { static constexpr int N = (MAXW <= 8) ? 3 : 2; };
 constexpr int kVmcnt0 = 0x0F70;     // s_waitcnt immediate: vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
 constexpr int RINGN = 64;
 
 // Diagnostic build only (make STAMPS=1): per-segment s_memtime sums of the steady-state slot of wave 0 of
 // workgroup 0, read back through ftr_debug_stamps().  Never compiled into the product library.
-static __device__ unsigned long long g_stamps[16];  // one copy per translation unit; the duo file's is read back
+static __device__ unsigned long long g_stamps[16];  // read back by debug_stamps()
 #ifdef FTR_STAMPS
 #define FTR_STAMP(var)                                                                            \
   do {                                                                                            \

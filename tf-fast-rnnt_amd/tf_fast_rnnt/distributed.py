@@ -48,19 +48,29 @@ def shard_batch(B: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def reduce_loss(local_loss_none: torch.Tensor, reduction: str = "mean", group=None) -> torch.Tensor:
+def reduce_loss(local_loss_none: torch.Tensor, reduction: str = "mean", group=None,
+                grad_averaging: bool = False) -> torch.Tensor:
     """Combine per-utterance losses (reduction="none" output of any loss driver, this rank's shard) into
     the value the single-device call would return for the whole batch: exactly one all-reduce of 2 floats.
 
     The returned scalar has the global VALUE on every rank and the LOCAL gradient: d/d(loss of a local
-    utterance) is 1 ("sum") or 1/global_count ("mean"), so that after every rank calls backward() and the
-    caller's data-parallel gradient all-reduce sums parameter gradients over ranks, the result equals the
-    single-device gradient (the replicated scalar is not counted world_size times)."""
+    utterance) is 1 ("sum") or 1/global_count ("mean").
+
+    WHAT THE CALLER'S GRADIENT EXCHANGE MUST DO.  With ``grad_averaging=False`` (default) the parameter gradients
+    must be SUMMED over ranks (a plain all-reduce SUM): the sum of the local gradients is the single-device
+    gradient (the replicated scalar is not counted world_size times).  ``torch.nn.parallel.DistributedDataParallel``
+    AVERAGES gradients instead; pass ``grad_averaging=True`` there: the local gradient is multiplied by the world
+    size (the value is unchanged) so that the average over ranks is again the single-device gradient.  The same
+    factor reaches the smoothed builder's all-reduced unigram gradient (``get_rnnt_logprobs_smoothed(process_group=)``),
+    which is linear in the upstream gradient."""
     if reduction not in ("mean", "sum"):
         raise ValueError("reduce_loss supports 'mean' and 'sum'")
     local_sum = local_loss_none.sum()
     packed = torch.stack((local_sum.detach(), local_sum.new_tensor(float(local_loss_none.numel()))))
+    world = 1
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    total = local_sum + (packed[0] - local_sum.detach())      # global value, local gradient
+    grad_part = local_sum * float(world) if (grad_averaging and world > 1) else local_sum
+    total = grad_part + (packed[0] - grad_part.detach())      # global value, local (optionally world-scaled) gradient
     return total if reduction == "sum" else total / packed[1]
