@@ -41,19 +41,36 @@ const char* ftr_package_version(void);
 const char* ftr_last_error(void);
 /* Selects the mutual-information kernel family: 0 = "wavefront" (default: skewed wave64 DP, one workgroup per
  * 64-row band, bands chained through tagged granules, the recursion run from both ends of the lattice towards a
- * cut in the middle; mi_wave_bidir.hip), 1 = "plain" (one thread per lattice row, reference arithmetic),
- * 2 = "mono", 3 = "duo" (earlier single-workgroup wavefront variants: mono up to 1024 rows, duo up to 384),
- * 4 = "chain" (the banded wavefront run from one end only; mi_wave_chain.hip) -- 2..4 are kept for bisecting.
- * Also settable with FTR_MI_IMPL=wavefront|plain|mono|duo|chain.  Returns the previous value. */
+ * cut in the middle; mi_wave_bidir.hip), 1 = "plain" (one thread per lattice row, the reference's arithmetic on the
+ * device, up to 1024 rows: a bisecting aid, not a product path).  Also settable with FTR_MI_IMPL=wavefront|plain.
+ * Returns the previous value. */
 int ftr_set_mi_impl(int impl);
 int ftr_get_mi_impl(void);
 
-/* Number of floats of fwd->bwd workspace (`p` below) for a problem size: about two lattices of the shape of the
- * reference's temp `p` (tf_fast_rnnt_op.cc:65-67; one split-ratio lattice per direction of the recursion), the
- * values on the cut, and a small inter-workgroup hand-off region.  Its CONTENT is implementation defined (see
- * DESIGN.md section 4): the same buffer must be handed unchanged from _fwd to _bwd (the backward reuses the hand-off
- * region as scratch).  Must be 16-byte aligned. */
+/* Number of floats of fwd->bwd workspace (`p` below) for a problem size.  `p` is NOT the reference's [B,S+1,T+1] temp
+ * (tf_fast_rnnt_op.cc:65-67): it is about TWO lattices of that shape (one split-ratio lattice per direction of the
+ * recursion), the values on the cut, and an inter-workgroup hand-off region -- a buffer of B*(S+1)*(T+1) floats is too
+ * small and the kernels would write past its end.  Callers that cannot guarantee the size use the _ws entry points
+ * below, which check it.  Its CONTENT is implementation defined: the same buffer must be handed
+ * unchanged from _fwd to _bwd.  Must be 16-byte aligned. */
 size_t ftr_mutual_information_workspace_floats(int B, int S, int T);
+
+/* flags of the _ws entry points */
+#define FTR_MI_WS_CLEAN 1 /* the hand-off region of `p` is known to be all zero: it was zeroed once by
+                             ftr_mutual_information_workspace_init() and since then only touched by launches of this
+                             library that completed with status 0 (they leave it zero again).  Saves the memset node
+                             in front of the forward launch.  The promise holds for the (B,S,T) the buffer was
+                             initialised for; graph capture / replay is fine (nothing depends on a launch counter). */
+
+/* Zeroes the hand-off region of a workspace (asynchronous on `stream`).  Once per buffer and problem size. */
+int ftr_mutual_information_workspace_init(float* p, size_t p_floats, int B, int S, int T, void* stream);
+
+/* Reads back the sticky status word of a workspace (SYNCHRONISES `stream`): 0 = fine; bit 0 = some band gave up
+ * waiting for the band above it (bounded poll; cannot happen unless a producer workgroup never ran): the results of
+ * that launch are poisoned (ans = NaN) and the workspace must be re-initialised.  dirty_words_host (nullable,
+ * diagnostic) receives the number of non-zero words left in the hand-off region, which is 0 between launches. */
+int ftr_mutual_information_status(const float* p, size_t p_floats, int B, int S, int T, int* status_host,
+                                  long long* dirty_words_host, void* stream);
 
 /*
  * Forward recursion.  Replaces MutualInformationCuda<float>
@@ -61,11 +78,21 @@ size_t ftr_mutual_information_workspace_floats(int B, int S, int T);
  *   px [B,S,T+1] (modified==0) or [B,S,T] (modified!=0); py [B,S+1,T];
  *   boundary [B,4] = (s_begin,t_begin,s_end,t_end) or NULL => (0,0,S,T);
  *   p   workspace, ftr_mutual_information_workspace_floats() floats, written;
- *   ans [B] = p[b,s_end,t_end] of the recursion documented at mutual_information.h:101-126.
+ *   ans [B] = p[b,s_end,t_end] of the recursion documented at mutual_information.h:101-126; 0 for an empty
+ *       rectangle; -inf when no path exists.
+ * NaN inputs: the reference's LogAdd (mutual_information.h:70-83) lets a NaN through or drops it depending on which
+ * argument it arrives in; here ANY NaN among the px / py entries inside the boundary rectangle of utterance b gives
+ * ans[b] = NaN (and zero occupancies), so that a diverged model is seen.  -inf entries are ordinary ("impossible
+ * transition").
+ * The _ws form takes the size of `p` (returns FTR_ERR_INVALID_ARG when it is too small instead of writing past it)
+ * and the FTR_MI_* flags; the plain form trusts the caller and passes no flags.
  */
 int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary,
                                    float* p, float* ans, int B, int S, int T, int modified,
                                    void* stream);
+int ftr_mutual_information_fwd_ws_f32(const float* px, const float* py, const int32_t* boundary, float* p,
+                                      size_t p_floats, int flags, float* ans, int B, int S, int T, int modified,
+                                      void* stream);
 
 /*
  * Backward recursion.  Replaces MutualInformationBackwardCuda<float>
@@ -84,6 +111,10 @@ int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32
                                    const float* p, float* p_grad, float* px_grad, float* py_grad,
                                    float* ans_grad, int overwrite_ans_grad, int B, int S, int T,
                                    int modified, void* stream);
+int ftr_mutual_information_bwd_ws_f32(const float* px, const float* py, const int32_t* boundary, const float* p,
+                                      size_t p_floats, int flags, float* p_grad, float* px_grad, float* py_grad,
+                                      float* ans_grad, int overwrite_ans_grad, int B, int S, int T, int modified,
+                                      void* stream);
 
 /* Inclusive prefix-min along rows of an int32 [rows, cols] matrix.  Replaces CumminCuda<int32_t>
  * (mutual_information.h:164-168, mutual_information_cuda.cu:895-1012; op "Cummin",

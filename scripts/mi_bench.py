@@ -18,7 +18,10 @@ def run(B, S, T, iters=20, impl=0, cold=False):
     bd = torch.zeros((B, 4), dtype=torch.int32); bd[:, 2] = S; bd[:, 3] = T
     px[:, :, T] = float("-inf")
     bd = bd.to(dev)
-    ws = torch.empty(L.ftr_mutual_information_workspace_floats(B, S, T), dtype=torch.float32, device=dev)
+    nws = L.ftr_mutual_information_workspace_floats(B, S, T)
+    ws = torch.empty(nws, dtype=torch.float32, device=dev)
+    _lib.call("ftr_mutual_information_workspace_init", _ptr(ws), nws, B, S, T, torch.cuda.current_stream().cuda_stream)
+    product = impl == 0 and not os.environ.get("FTR_BENCH_LEGACY_CALLS")   # what the package does: clean cached workspace, seed = ones
     pg = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=dev) if impl == 1 else None
     ans = torch.empty(B, device=dev); ag = torch.ones(B, device=dev)
     gx = torch.empty_like(px); gy = torch.empty_like(py)
@@ -29,9 +32,15 @@ def run(B, S, T, iters=20, impl=0, cold=False):
         if cold: flush.fill_(1.0)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
-        _lib.call("ftr_mutual_information_fwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(ans), B, S, T, 0, st)
+        if product:
+            _lib.call("ftr_mutual_information_fwd_ws_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), nws, 1, _ptr(ans), B, S, T, 0, st)
+        else:
+            _lib.call("ftr_mutual_information_fwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(ans), B, S, T, 0, st)
         e[1].record()
-        _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(pg), _ptr(gx), _ptr(gy), _ptr(ag), 1, B, S, T, 0, st)
+        if product:
+            _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), nws, 1, None, _ptr(gx), _ptr(gy), None, 0, B, S, T, 0, st)
+        else:
+            _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(pg), _ptr(gx), _ptr(gy), _ptr(ag), 1, B, S, T, 0, st)
         e[2].record()
         torch.cuda.synchronize()
         if i >= 3:

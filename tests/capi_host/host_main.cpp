@@ -1,0 +1,103 @@
+// tests/capi_host/host_main.cpp -- a non-Python host of the C ABI (include/ftr.h): plain C++ + the HIP runtime, no torch.
+// Stand-in for the reference-side TF op shim that cannot be built in this image (tf_fast_rnnt/python/csrc/
+// tf_fast_rnnt_op.cc:48-165 does exactly this: allocate temps/outputs, call forward, call backward with ones, return):
+// it runs ftr_mutual_information_{fwd,bwd}_ws_f32, ftr_cummin_i32 and ftr_prune_ranges_i32 on raw files written by
+// tests/test_gpu_capi_host.py from a golden fixture and writes the outputs back for the test to compare.
+//
+//   capi_host.bin <dir> B S T modified s_range cummin_rows cummin_cols
+//   in : <dir>/px.bin py.bin boundary.bin gx.bin gy.bin cummin_in.bin      out: ans.bin px_grad.bin py_grad.bin
+//                                                                               ans_grad.bin cummin_out.bin ranges.bin
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include "../../include/ftr.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(3); } } while (0)
+#define FTR_CALL(x) do { int rc_ = (x); if (rc_ != FTR_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, ftr_last_error()); exit(4); } } while (0)
+
+template <typename T>
+static std::vector<T> read_file(const std::string& path, size_t n) {
+  std::vector<T> v(n);
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f || fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "cannot read %zu items from %s\n", n, path.c_str()); exit(2); }
+  fclose(f);
+  return v;
+}
+template <typename T>
+static void write_file(const std::string& path, const T* dev, size_t n) {
+  std::vector<T> v(n);
+  HIP_OK(hipMemcpy(v.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost));
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f || fwrite(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(2); }
+  fclose(f);
+}
+template <typename T>
+static T* to_device(const std::vector<T>& v) {
+  T* d = nullptr;
+  HIP_OK(hipMalloc(&d, (v.size() ? v.size() : 1) * sizeof(T)));
+  if (!v.empty()) HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+template <typename T>
+static T* device_alloc(size_t n) { T* d = nullptr; HIP_OK(hipMalloc(&d, (n ? n : 1) * sizeof(T))); return d; }
+
+int main(int argc, char** argv) {
+  if (argc != 9) { fprintf(stderr, "usage: %s dir B S T modified s_range cummin_rows cummin_cols\n", argv[0]); return 1; }
+  const std::string dir = argv[1];
+  const int B = atoi(argv[2]), S = atoi(argv[3]), T = atoi(argv[4]), modified = atoi(argv[5]), s_range = atoi(argv[6]);
+  const int crows = atoi(argv[7]), ccols = atoi(argv[8]);
+  const int T1 = modified ? T : T + 1;
+  const size_t npx = (size_t)B * S * T1, npy = (size_t)B * (S + 1) * T;
+  if (ftr_abi_version() < 110) { fprintf(stderr, "library ABI %d too old\n", ftr_abi_version()); return 5; }
+
+  hipStream_t st;
+  HIP_OK(hipStreamCreate(&st));
+  float* px = to_device(read_file<float>(dir + "/px.bin", npx));
+  float* py = to_device(read_file<float>(dir + "/py.bin", npy));
+  int32_t* bd = to_device(read_file<int32_t>(dir + "/boundary.bin", (size_t)B * 4));
+
+  // FastRNNTOpBase::Compute (tf_fast_rnnt_op.cc:59-112): temp p, outputs, forward, ones, backward
+  const size_t p_floats = ftr_mutual_information_workspace_floats(B, S, T);
+  float* p = device_alloc<float>(p_floats);
+  float* ans = device_alloc<float>(B);
+  float* px_grad = device_alloc<float>(npx);
+  float* py_grad = device_alloc<float>(npy);
+  float* ans_grad = to_device(std::vector<float>(B, 1.0f));
+  // an undersized workspace must be refused, not written past (what a {B,S+1,T+1} temp would be)
+  if (ftr_mutual_information_fwd_ws_f32(px, py, bd, p, (size_t)B * (S + 1) * (T + 1), 0, ans, B, S, T, modified, st) != FTR_ERR_INVALID_ARG) {
+    fprintf(stderr, "an undersized workspace was accepted\n"); return 6;
+  }
+  FTR_CALL(ftr_mutual_information_fwd_ws_f32(px, py, bd, p, p_floats, 0, ans, B, S, T, modified, st));
+  FTR_CALL(ftr_mutual_information_bwd_ws_f32(px, py, bd, p, p_floats, 0, nullptr, px_grad, py_grad, ans_grad, 1, B, S, T, modified, st));
+
+  // Cummin op (tf_fast_rnnt_op.cc:135-165)
+  int32_t* cin = to_device(read_file<int32_t>(dir + "/cummin_in.bin", (size_t)crows * ccols));
+  int32_t* cout_ = device_alloc<int32_t>((size_t)crows * ccols);
+  FTR_CALL(ftr_cummin_i32(cin, cout_, crows, ccols, st));
+
+  // get_rnnt_prune_ranges (rnnt_loss.py:647-761) on the fixture's occupancies
+  float* gx = to_device(read_file<float>(dir + "/gx.bin", npx));
+  float* gy = to_device(read_file<float>(dir + "/gy.bin", npy));
+  int r_eff = 0;
+  const int r_max = s_range > S ? S + 1 : s_range;
+  int32_t* ranges = device_alloc<int32_t>((size_t)B * T * r_max);
+  int32_t* scratch = device_alloc<int32_t>((size_t)B * T);
+  FTR_CALL(ftr_prune_ranges_i32(gx, gy, bd, ranges, scratch, B, S, T, T1, s_range, &r_eff, st));
+  if (r_eff != r_max) { fprintf(stderr, "r_eff %d != %d\n", r_eff, r_max); return 7; }
+
+  HIP_OK(hipStreamSynchronize(st));
+  int status = -1;
+  FTR_CALL(ftr_mutual_information_status(p, p_floats, B, S, T, &status, nullptr, st));
+  if (status != 0) { fprintf(stderr, "workspace status word %d\n", status); return 8; }
+  write_file(dir + "/ans.bin", ans, (size_t)B);
+  write_file(dir + "/px_grad.bin", px_grad, npx);
+  write_file(dir + "/py_grad.bin", py_grad, npy);
+  write_file(dir + "/ans_grad.bin", ans_grad, (size_t)B);
+  write_file(dir + "/cummin_out.bin", cout_, (size_t)crows * ccols);
+  write_file(dir + "/ranges.bin", ranges, (size_t)B * T * r_eff);
+  printf("capi_host OK: B=%d S=%d T=%d modified=%d r=%d workspace %zu floats\n", B, S, T, modified, r_eff, p_floats);
+  return 0;
+}

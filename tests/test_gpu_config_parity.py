@@ -1,0 +1,213 @@
+"""Oracle parity at the EXACT shapes of the BASELINE.json configs, so that no config is untested and the
+north_star tolerance ("ranges bit-exact; loss and px/py gradients within 1e-4 relative") is stated with measured numbers:
+
+  c2  rnnt_loss_simple fwd+bwd, B=32 T=512 S=100 C=500            full size
+  c3  pruned pipeline, T=1000 S=200 C=500 s_range=5               a B=2 batch slice at full T, S, C, r
+  c5  long form, T=8000 S=1000 C=512 s_range=10                   a B=1 slice at full T, S, C, r + the full B=8 pipeline
+                                                                  through size-independent properties
+  (c1 and the reference test scenario: tests/golden fixtures, test_gpu_pipeline.py; c4: its per-GPU share there.)
+
+Every comparison records two error figures against the float32 oracle (= the reference's arithmetic) and against the
+float64 oracle: normwise  max|d| / max|ref|  and elementwise  max over entries with |ref| > 1e-6 max|ref|  of
+|d| / |ref|.  The session writes them to gpurun_out/parity_errors.json (committed as profiles/r02_parity_errors.json).
+
+What is asserted.  Integer outputs: bit-exact.  Losses: 1e-4 elementwise against the float32 oracle.  Float lattices /
+gradients: normwise <= 1e-4 against the float32 oracle, or -- on lattices where the reference's own float32 arithmetic is
+further than that from float64 -- at least as close to the float64 oracle as the float32 oracle is.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_parity, max_rel, synthetic
+
+pytestmark = pytest.mark.gpu
+
+_LOG = {}
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _elem_rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    if not fin.any():
+        return 0.0
+    big = fin & (np.abs(b) > 1e-6 * np.max(np.abs(b[fin])))
+    if not big.any():
+        return 0.0
+    return float(np.max(np.abs(a[big] - b[big]) / np.abs(b[big])))
+
+
+def _record(config, what, got, ref32, ref64=None):
+    e = dict(normwise_vs_f32=max_rel(got, ref32), elementwise_vs_f32=_elem_rel(got, ref32))
+    if ref64 is not None:
+        e.update(normwise_vs_f64=max_rel(got, ref64), elementwise_vs_f64=_elem_rel(got, ref64),
+                 f32_oracle_normwise_vs_f64=max_rel(ref32, ref64), f32_oracle_elementwise_vs_f64=_elem_rel(ref32, ref64))
+    _LOG.setdefault(config, {})[what] = {k: float(f"{v:.3e}") for k, v in e.items()}
+    return e
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_log():
+    yield
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(_LOG, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _simple_pass_f64(oracle, d, px32, py32):
+    """float64 comparison point of the simple pass: float64 px/py builder, float64 recursion, and d am / d lm by
+    float64 torch autograd through the op-by-op restatement (occupancies chained into the builder)."""
+    from torch_restatements import get_rnnt_logprobs_torch
+    lm = torch.from_numpy(d["lm"]).double().requires_grad_(True)
+    am = torch.from_numpy(d["am"]).double().requires_grad_(True)
+    sym = torch.from_numpy(d["symbols"]); bd = torch.from_numpy(d["boundary"])
+    px, py = get_rnnt_logprobs_torch(lm, am, sym, d["termination_symbol"], "regular", bd)
+    a64, (gx64, gy64) = oracle.mutual_information_recursion(px.detach().numpy(), py.detach().numpy(), d["boundary"], True, np.float64)
+    fin = torch.isfinite(px)
+    tot = -((torch.where(fin, px, torch.zeros_like(px)) * torch.from_numpy(gx64) * fin).sum() + (py * torch.from_numpy(gy64)).sum())
+    tot.backward()
+    return a64, gx64, gy64, am.grad.numpy(), lm.grad.numpy()
+
+
+def _check_simple_pass(ft, dev, oracle, config, d, tol_f64):
+    blank = d["termination_symbol"]
+    am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+    sym, bd = _t(d["symbols"], dev), _t(d["boundary"], dev)
+    loss, (gx, gy) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank, boundary=bd,
+                                         reduction="none", calc_gradients=True)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], blank, "regular", d["boundary"])
+    o_ans, (o_gx, o_gy) = oracle.mutual_information_recursion(o_px, o_py, d["boundary"], True)
+    a64, gx64, gy64, dam64, dlm64 = _simple_pass_f64(oracle, d, o_px, o_py)
+    loss_np, gx_np, gy_np = loss.detach().cpu().numpy(), gx.cpu().numpy(), gy.cpu().numpy()
+    _record(config, "simple_loss", loss_np, -o_ans, -a64)
+    np.testing.assert_allclose(loss_np, -o_ans, rtol=1e-4)
+    np.testing.assert_allclose(loss_np, -a64, rtol=1e-4)
+    for name, got, r32, r64 in (("px_grad", gx_np, o_gx, gx64), ("py_grad", gy_np, o_gy, gy64)):
+        e = _record(config, "simple_" + name, got, r32, r64)
+        assert_parity(got, r32, r64.astype(np.float32), what=f"{config} {name}")
+        assert e["normwise_vs_f64"] <= tol_f64, (config, name, e)
+    # d loss / d am, d lm (hand-written backward of the builder + GEMMs) against float64 autograd
+    for name, got, r64 in (("d_am", am.grad.cpu().numpy(), dam64), ("d_lm", lm.grad.cpu().numpy(), dlm64)):
+        e = dict(normwise_vs_f64=max_rel(got, r64), elementwise_vs_f64=_elem_rel(got, r64))
+        _LOG.setdefault(config, {})["simple_" + name] = {k: float(f"{v:.3e}") for k, v in e.items()}
+        assert e["normwise_vs_f64"] <= max(1e-4, tol_f64), (config, name, e)
+    return gx_np, gy_np, o_gx, o_gy
+
+
+def _check_pruned_pass(ft, dev, oracle, config, d, r, o_gx, o_gy, tol_f64):
+    blank = d["termination_symbol"]
+    sym, bd = _t(d["symbols"], dev), _t(d["boundary"], dev)
+    # ranges: integer function of the occupancies -> bit-exact on identical (oracle) occupancies
+    o_ranges = oracle.get_rnnt_prune_ranges(o_gx, o_gy, d["boundary"], r)
+    ranges = ft.get_rnnt_prune_ranges(_t(o_gx, dev), _t(o_gy, dev), bd, r)
+    assert np.array_equal(ranges.cpu().numpy(), o_ranges), f"{config}: prune ranges differ"
+    am_p, lm_p = ft.do_rnnt_pruning(_t(d["am"], dev), _t(d["lm"], dev), ranges)
+    o_am_p, o_lm_p = oracle.do_rnnt_pruning(d["am"], d["lm"], o_ranges)
+    assert np.array_equal(am_p.cpu().numpy(), o_am_p) and np.array_equal(lm_p.cpu().numpy(), o_lm_p), f"{config}: gather differs"
+    logits_np = (1.0 / (1.0 + np.exp(-(o_am_p + o_lm_p)))).astype(np.float32)       # the reference test's joiner stand-in
+    del o_am_p, o_lm_p, am_p, lm_p
+    logits = _t(logits_np, dev).requires_grad_(True)
+    ppx, ppy = ft.get_rnnt_logprobs_pruned(logits.detach(), sym, ranges, blank, bd)
+    o_ppx, o_ppy = oracle.get_rnnt_logprobs_pruned(logits_np, d["symbols"], o_ranges, blank, d["boundary"])
+    assert np.array_equal(np.isneginf(ppx.cpu().numpy()), np.isneginf(o_ppx)) and np.array_equal(np.isneginf(ppy.cpu().numpy()), np.isneginf(o_ppy))
+    e = _record(config, "pruned_px", ppx.cpu().numpy(), o_ppx); assert e["normwise_vs_f32"] <= 1e-5
+    e = _record(config, "pruned_py", ppy.cpu().numpy(), o_ppy); assert e["normwise_vs_f32"] <= 1e-5
+    del ppx, ppy, o_ppx, o_ppy
+    pl = ft.rnnt_loss_pruned(logits, sym, ranges, blank, bd, reduction="sum")
+    pl.backward()
+    torch.cuda.synchronize()
+    o_pl, o_g = oracle.rnnt_loss_pruned_grad(logits_np, d["symbols"], o_ranges, blank, d["boundary"], reduction="sum")
+    o_pl64, o_g64 = oracle.rnnt_loss_pruned_grad(logits_np, d["symbols"], o_ranges, blank, d["boundary"], reduction="sum", dtype=np.float64)
+    _record(config, "pruned_loss", np.array([pl.item()]), np.array([o_pl]), np.array([o_pl64]))
+    np.testing.assert_allclose(pl.item(), o_pl, rtol=1e-4)
+    g = logits.grad.cpu().numpy()
+    e = _record(config, "pruned_logits_grad", g, o_g, o_g64)
+    assert_parity(g, o_g, o_g64, what=f"{config} d/d logits")
+    assert e["normwise_vs_f64"] <= tol_f64, (config, e)
+
+
+def test_c2_simple_loss_full_size(ft, dev, oracle):
+    """BASELINE configs[1]: rnnt_loss_simple fwd+bwd B=32 T=512 S=100 C=500, ragged boundaries, full size."""
+    d = synthetic(2, 32, 512, 100, 500, ragged=True)
+    _check_simple_pass(ft, dev, oracle, "c2_B32_T512_S100_C500", d, tol_f64=2e-4)
+
+
+def test_c3_pruned_pipeline_batch_slice(ft, dev, oracle):
+    """BASELINE configs[2] at full T, S, C, s_range with a B=2 slice (one full-size and one ragged utterance)."""
+    d = synthetic(3, 2, 1000, 200, 500, ragged=True)
+    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c3_B2_T1000_S200_C500_r5", d, tol_f64=5e-4)
+    _check_pruned_pass(ft, dev, oracle, "c3_B2_T1000_S200_C500_r5", d, 5, o_gx, o_gy, tol_f64=5e-4)
+
+
+def test_c5_long_form_batch_slice(ft, dev, oracle):
+    """BASELINE configs[4] at full T, S, C, s_range = 10 with a B=1 slice: simple pass, ranges, gather, pruned pass."""
+    d = synthetic(5, 1, 8000, 1000, 512, ragged=False)
+    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c5_B1_T8000_S1000_C512_r10", d, tol_f64=5e-3)
+    _check_pruned_pass(ft, dev, oracle, "c5_B1_T8000_S1000_C512_r10", d, 10, o_gx, o_gy, tol_f64=5e-3)
+
+
+def test_c5_full_size_pipeline_properties(ft, dev):
+    """BASELINE configs[4] at full size (B=8, T=8000, S=1000, C=512, s_range=10) end to end on the GPU through the
+    size-independent properties: ranges monotone / bounded / pinned at the last frame, occupancies sum to one per valid
+    frame, softmax-gradient rows sum to zero, everything finite."""
+    from bench import make_inputs, pruned_step
+    B, T, S, C, r = 8, 8000, 1000, 512, 10
+    inp = make_inputs(B=B, T=T, S=S, C=C, seed=4, device=dev, ragged=True)
+    out = pruned_step(inp, s_range=r, keep=True)
+    torch.cuda.synchronize()
+    ranges = out["ranges"].cpu().numpy()
+    bd = inp["boundary"].cpu().numpy()
+    s0 = ranges[:, :, 0]
+    assert (np.diff(s0, axis=1) >= 0).all() and (np.diff(s0, axis=1) <= r - 1).all() and (s0 >= 0).all() and (s0 <= S - r + 1).all()
+    assert (ranges == s0[:, :, None] + np.arange(r)).all()
+    for b in range(B):
+        assert s0[b, bd[b, 3] - 1] == max(bd[b, 2] - r + 1, 0)
+    pyg = out["py_grad"].sum(dim=1).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(pyg[b, :bd[b, 3]], 1.0, rtol=1e-3)
+        assert not pyg[b, bd[b, 3]:].any()
+    g = out["logits_grad"]
+    assert torch.isfinite(g).all() and torch.isfinite(out["pruned_loss"]).all() and torch.isfinite(out["simple_loss"]).all()
+    np.testing.assert_allclose(g.sum(dim=3).cpu().numpy(), 0.0, atol=5e-5)
+    assert torch.isfinite(out["am_grad"]).all() and torch.isfinite(out["lm_grad"]).all()
+    _LOG.setdefault("c5_B8_full_size", {})["properties"] = dict(
+        max_abs_frame_occupancy_minus_1=float(np.max([np.abs(pyg[b, :bd[b, 3]] - 1.0).max() for b in range(B)])),
+        max_abs_softmax_grad_row_sum=float(g.sum(dim=3).abs().max().item()))
+
+
+@pytest.mark.parametrize("shape", [(2, 50, 200), (2, 100, 512), (2, 200, 1000), (1, 400, 3000)])
+def test_recursion_accuracy_vs_float64(ft, dev, oracle, shape):
+    """The recursion alone on random lattices with realistic magnitudes (log-probs ~ N(-6,1)) against the float64 oracle:
+    the default (bidirectional) family must be at least as accurate as the reference's float32 arithmetic (float32
+    oracle; the `plain` family runs the same arithmetic on the device)."""
+    from tf_fast_rnnt.mutual_information import mi_forward_backward
+    B, S, T = shape
+    rng = np.random.default_rng(S + T)
+    px = (rng.standard_normal((B, S, T + 1)) - 6.0).astype(np.float32); px[:, :, T] = -np.inf
+    py = (rng.standard_normal((B, S + 1, T)) - 6.0).astype(np.float32)
+    bd = np.zeros((B, 4), np.int32); bd[:, 2] = S; bd[:, 3] = T
+    a64, p64 = oracle.mi_forward(px, py, bd, dtype=np.float64); gx64, gy64, _ = oracle.mi_backward(px, py, bd, p64, dtype=np.float64)
+    a32, p32 = oracle.mi_forward(px, py, bd); gx32, gy32, _ = oracle.mi_backward(px, py, bd, p32)
+    ans, gx, gy = mi_forward_backward(_t(px, dev), _t(py, dev), _t(bd, dev), True)
+    torch.cuda.synchronize()
+    key = f"recursion_B{B}_S{S}_T{T}"
+    _record(key, "ans", ans.cpu().numpy(), a32, a64)
+    ex = _record(key, "px_grad", gx.cpu().numpy(), gx32, gx64)
+    ey = _record(key, "py_grad", gy.cpu().numpy(), gy32, gy64)
+    np.testing.assert_allclose(ans.cpu().numpy(), a64, rtol=1e-4)
+    for e in (ex, ey):
+        assert e["normwise_vs_f64"] <= max(1e-4, e["f32_oracle_normwise_vs_f64"]), (key, e)

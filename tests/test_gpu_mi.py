@@ -233,3 +233,157 @@ def test_mi_launches_are_bit_reproducible(ft, dev, cfg):
             assert torch.isfinite(ref[0]).all()
         else:
             assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
+def _raw_ws_calls(ft, dev, px, py, bd, ws, flags, modified=0, lib=None):
+    """forward + backward through the _ws entry points on a caller-managed workspace."""
+    from tf_fast_rnnt import _lib
+    L = lib or _lib.lib()
+    B, S, T1 = px.shape
+    T = py.shape[2]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ans = torch.empty(B, device=dev); gx = torch.empty_like(px); gy = torch.empty_like(py)
+    ag = torch.ones(B, device=dev)
+    rc = L.ftr_mutual_information_fwd_ws_f32(px.data_ptr(), py.data_ptr(), bd.data_ptr(), ws.data_ptr(), ws.numel(), flags,
+                                             ans.data_ptr(), B, S, T, modified, st)
+    assert rc == 1, L.ftr_last_error()
+    rc = L.ftr_mutual_information_bwd_ws_f32(px.data_ptr(), py.data_ptr(), bd.data_ptr(), ws.data_ptr(), ws.numel(), flags,
+                                             None, gx.data_ptr(), gy.data_ptr(), ag.data_ptr(), 1, B, S, T, modified, st)
+    assert rc == 1, L.ftr_last_error()
+    return ans, gx, gy, ag
+
+
+def _status(ft, dev, ws, B, S, T, lib=None):
+    import ctypes
+    from tf_fast_rnnt import _lib
+    L = lib or _lib.lib()
+    stt = ctypes.c_int(-1); dirty = ctypes.c_longlong(-1)
+    rc = L.ftr_mutual_information_status(ws.data_ptr(), ws.numel(), B, S, T, ctypes.byref(stt), ctypes.byref(dirty),
+                                         torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 1
+    return stt.value, dirty.value
+
+
+@pytest.mark.parametrize("modified", [0, 1])
+def test_workspace_stays_clean_across_launches(ft, dev, modified):
+    """The hand-off region is left all-zero by every launch (each consumer clears what it imported, the last band of an
+    utterance clears its counters), whatever the boundaries were: one workspace initialised once and then used with
+    FTR_MI_WS_CLEAN for a sequence of DIFFERENT boundaries gives bit-identical results to fresh, memset-per-call runs."""
+    from tf_fast_rnnt import _lib
+    L = _lib.lib()
+    B, S, T = 6, 200, 300
+    g = torch.Generator(device="cpu").manual_seed(1)
+    px = (torch.randn((B, S, T if modified else T + 1), generator=g) - 4.0).to(dev)
+    py = (torch.randn((B, S + 1, T), generator=g) - 4.0).to(dev)
+    n = L.ftr_mutual_information_workspace_floats(B, S, T)
+    ws = torch.full((n,), float("nan"), device=dev)        # garbage everywhere outside the region init clears
+    st = torch.cuda.current_stream(dev).cuda_stream
+    assert L.ftr_mutual_information_workspace_init(ws.data_ptr(), n, B, S, T, st) == 1
+    rng = np.random.default_rng(0)
+    for it in range(6):
+        bd = torch.zeros((B, 4), dtype=torch.int32)
+        bd[:, 2] = torch.from_numpy(rng.integers(0, S + 1, B).astype(np.int32))
+        bd[:, 3] = torch.from_numpy(rng.integers(1, T + 1, B).astype(np.int32))
+        if it == 0:
+            bd[:, 2] = S; bd[:, 3] = T
+        bd[0, 0] = min(3, int(bd[0, 2])); bd[0, 1] = min(5, int(bd[0, 3]))
+        bd = bd.to(dev)
+        got = _raw_ws_calls(ft, dev, px, py, bd, ws, _lib.FTR_MI_WS_CLEAN, modified)
+        stt, dirty = _status(ft, dev, ws, B, S, T)
+        assert stt == 0 and dirty == 0, (it, stt, dirty)
+        fresh = torch.full((n,), float("nan"), device=dev)
+        want = _raw_ws_calls(ft, dev, px, py, bd, fresh, 0, modified)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
+def test_undersized_workspace_is_refused(ft, dev):
+    """A buffer of the reference's p shape [B,S+1,T+1] is too small for the two-lattice workspace: the _ws entry points
+    return FTR_ERR_INVALID_ARG instead of writing past its end."""
+    from tf_fast_rnnt import _lib
+    L = _lib.lib()
+    B, S, T = 2, 30, 40
+    px = torch.zeros((B, S, T + 1), device=dev); py = torch.zeros((B, S + 1, T), device=dev)
+    small = torch.empty(B * (S + 1) * (T + 1), device=dev)
+    ans = torch.empty(B, device=dev)
+    rc = L.ftr_mutual_information_fwd_ws_f32(px.data_ptr(), py.data_ptr(), None, small.data_ptr(), small.numel(), 0,
+                                             ans.data_ptr(), B, S, T, 0, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0 and b"workspace" in L.ftr_last_error()
+
+
+@pytest.mark.parametrize("cfg", [(160, 200, 300, False), (64, 1000, 2000, False), (300, 130, 90, True)])
+def test_oversubscribed_grid(ft, dev, oracle, cfg):
+    """More workgroups than the chip holds at once (1280 / 2048 / 1800 here; one workgroup per CU while the grid fits,
+    a few per CU beyond): bands still only wait for bands with lower block ids, which were dispatched earlier.  Checked
+    against the oracle on a few utterances and through the occupancy invariants on all."""
+    from tf_fast_rnnt.mutual_information import mi_forward_backward
+    B, S, T, mod = cfg
+    g = torch.Generator(device="cpu").manual_seed(B)
+    px = (torch.randn((B, S, T if mod else T + 1), generator=g) - 5.0)
+    py = (torch.randn((B, S + 1, T), generator=g) - 5.0)
+    bd = torch.zeros((B, 4), dtype=torch.int32); bd[:, 2] = S; bd[:, 3] = T
+    bd[1, 2] = S // 2; bd[1, 3] = T // 2 + 1
+    if mod:
+        bd[:, 2] = torch.minimum(bd[:, 2], bd[:, 3])
+    ans, gx, gy, chk = mi_forward_backward(px.to(dev), py.to(dev), bd.to(dev), True, return_ans_grad_check=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ans).all()
+    np.testing.assert_allclose(chk.cpu().numpy(), 1.0, rtol=1e-3)
+    gyn = gy.cpu().numpy(); gxn = gx.cpu().numpy()
+    for b in range(B):     # every frame is left exactly once: through a py transition, or (modified) through a px one
+        te, se = int(bd[b, 3]), int(bd[b, 2])
+        left = gyn[b, :se + 1, :te].sum(axis=0) + (gxn[b, :se, :te].sum(axis=0) if mod else 0.0)
+        np.testing.assert_allclose(left, 1.0, rtol=1e-3)
+    sel = [0, 1, B - 1]
+    o_ans, o_p = oracle.mi_forward(px[sel].numpy(), py[sel].numpy(), bd[sel].numpy(), dtype=np.float64)
+    o_gx, o_gy, _ = oracle.mi_backward(px[sel].numpy(), py[sel].numpy(), bd[sel].numpy(), o_p, dtype=np.float64)
+    np.testing.assert_allclose(ans.cpu().numpy()[sel], o_ans, rtol=1e-4)
+    assert max_rel(gx.cpu().numpy()[sel], o_gx.astype(np.float32)) <= 2e-3 and max_rel(gyn[sel], o_gy.astype(np.float32)) <= 2e-3
+
+
+def test_nan_inputs_give_nan_ans(ft, dev, oracle):
+    """Documented deviation (include/ftr.h): a NaN anywhere among the px / py entries inside the boundary rectangle of an
+    utterance gives ans = NaN for that utterance (the reference's LogAdd drops or keeps a NaN depending on the argument
+    it arrives in); the other utterances of the batch are unaffected."""
+    from tf_fast_rnnt.mutual_information import mi_forward_backward
+    px, py, bd = random_lattice(9, 5, 140, 180, ragged=False)
+    px[1, 70, 90] = np.nan
+    py[3, 139, 3] = np.nan
+    py[4, 10, 179] = np.nan      # inside the rectangle (t < t_end)
+    px[2, 5, 180] = np.nan       # column t == T of px is inside the rectangle as well (regular type)
+    ans, gx, gy = mi_forward_backward(torch.from_numpy(px).to(dev), torch.from_numpy(py).to(dev), torch.from_numpy(bd).to(dev), True)
+    torch.cuda.synchronize()
+    a = ans.cpu().numpy()
+    assert np.isnan(a[[1, 2, 3, 4]]).all() and np.isfinite(a[0])
+    o_ans, _ = oracle.mi_forward(px[:1], py[:1], bd[:1])
+    np.testing.assert_allclose(a[0], o_ans[0], rtol=1e-4)
+    assert not torch.isnan(gx[0]).any() and not torch.isnan(gy[0]).any()
+    # a second launch on the (cached, self-cleaned) workspace with clean inputs: no flag survives
+    px2, py2, _ = random_lattice(10, 5, 140, 180, ragged=False)
+    ans2, _, _ = mi_forward_backward(torch.from_numpy(px2).to(dev), torch.from_numpy(py2).to(dev), torch.from_numpy(bd).to(dev), True)
+    assert torch.isfinite(ans2).all()
+
+
+def test_absent_producer_poisons_loudly(ft, dev):
+    """Test build of the library in which the first alpha band never publishes its hand-off granules
+    (csrc/_build/libftr_nopublish.so, FTR_MAX_SPIN lowered): the consumer's bounded poll gives up, the launch terminates,
+    the sticky status word is set and every ans is NaN -- a stalled producer cannot go unnoticed."""
+    import ctypes, os
+    from tf_fast_rnnt import _lib
+    path = os.path.join(os.path.dirname(os.path.dirname(_lib.LIB_PATH)), "csrc", "_build", "libftr_nopublish.so")
+    assert os.path.exists(path), "run __graft_entry__.build()"
+    L = ctypes.CDLL(path)
+    for name in ("ftr_mutual_information_fwd_ws_f32", "ftr_mutual_information_bwd_ws_f32", "ftr_mutual_information_status",
+                 "ftr_mutual_information_workspace_floats", "ftr_last_error"):
+        getattr(L, name).restype, getattr(L, name).argtypes = _lib._SIGNATURES[name]
+    B, S, T = 3, 150, 200          # 3 bands per direction
+    g = torch.Generator(device="cpu").manual_seed(2)
+    px = (torch.randn((B, S, T + 1), generator=g) - 4.0).to(dev); py = (torch.randn((B, S + 1, T), generator=g) - 4.0).to(dev)
+    bd = torch.tensor([[0, 0, S, T]] * B, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.ftr_mutual_information_workspace_floats(B, S, T), device=dev)
+    ans, gx, gy, _ = _raw_ws_calls(ft, dev, px, py, bd, ws, 0, lib=L)
+    torch.cuda.synchronize()
+    stt, _ = _status(ft, dev, ws, B, S, T, lib=L)
+    assert stt == 1
+    assert torch.isnan(ans).all()

@@ -50,7 +50,7 @@ using namespace ftr;
 
 extern "C" {
 
-int ftr_abi_version(void) { return 100; }
+int ftr_abi_version(void) { return 110; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
@@ -68,38 +68,91 @@ size_t ftr_mutual_information_workspace_floats(int B, int S, int T) {
   return mi_bidir_workspace_floats(B, S, T);
 }
 
-int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary, float* p,
-                                   float* ans, int B, int S, int T, int modified, void* stream) {
+namespace {
+int mi_fwd_common(const char* what, const float* px, const float* py, const int32_t* boundary, float* p, size_t p_floats,
+                  int flags, float* ans, int B, int S, int T, int modified, void* stream) {
   clear_error();
-  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_fwd: negative size B=%d S=%d T=%d", B, S, T);
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "%s: negative size B=%d S=%d T=%d", what, B, S, T);
+  FTR_REQUIRE((flags & ~FTR_MI_WS_CLEAN) == 0, "%s: unknown flag bits 0x%x", what, flags);
   if (B == 0) return FTR_OK;
-  FTR_REQUIRE(py && p && ans, "mutual_information_fwd: null py/p/ans");
-  FTR_REQUIRE(px || S == 0 || (modified ? T == 0 : false), "mutual_information_fwd: null px");
+  FTR_REQUIRE(py && p && ans, "%s: null py/p/ans", what);
+  FTR_REQUIRE(px || S == 0 || (modified ? T == 0 : false), "%s: null px", what);
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (mi_impl() == 1) return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
-  return mi_bidir_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
+  if (mi_impl() == 1) {
+    FTR_REQUIRE(p_floats >= (size_t)B * (S + 1) * (T + 1), "%s: workspace too small for the plain family", what);
+    return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
+  }
+  return mi_bidir_fwd(px, py, boundary, p, p_floats, flags, ans, B, S, T, modified, st);
+}
+
+int mi_bwd_common(const char* what, const float* px, const float* py, const int32_t* boundary, const float* p,
+                  size_t p_floats, int flags, float* p_grad, float* px_grad, float* py_grad, float* ans_grad,
+                  int overwrite_ans_grad, int B, int S, int T, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "%s: negative size B=%d S=%d T=%d", what, B, S, T);
+  FTR_REQUIRE((flags & ~FTR_MI_WS_CLEAN) == 0, "%s: unknown flag bits 0x%x", what, flags);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(p && py_grad, "%s: null p/py_grad", what);
+  FTR_REQUIRE(ans_grad || mi_impl() == 0, "%s: ans_grad may be NULL (= ones) only with the default kernel family", what);
+  FTR_REQUIRE(px_grad || S == 0 || (modified && T == 0), "%s: null px_grad", what);
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (mi_impl() == 1) {
+    FTR_REQUIRE((px || S == 0) && py, "%s: the plain family needs px and py", what);
+    FTR_REQUIRE(p_grad, "%s: the plain family needs the p_grad scratch lattice", what);
+    return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
+  }
+  return mi_bidir_bwd(boundary, p, p_floats, flags, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
+}
+}  // namespace
+
+int ftr_mutual_information_fwd_f32(const float* px, const float* py, const int32_t* boundary, float* p,
+                                   float* ans, int B, int S, int T, int modified, void* stream) {
+  return mi_fwd_common("mutual_information_fwd", px, py, boundary, p, (size_t)-1, 0, ans, B, S, T, modified, stream);
 }
 
 int ftr_mutual_information_bwd_f32(const float* px, const float* py, const int32_t* boundary,
                                    const float* p, float* p_grad, float* px_grad, float* py_grad,
                                    float* ans_grad, int overwrite_ans_grad, int B, int S, int T,
                                    int modified, void* stream) {
+  return mi_bwd_common("mutual_information_bwd", px, py, boundary, p, (size_t)-1, 0, p_grad, px_grad, py_grad, ans_grad,
+                       overwrite_ans_grad, B, S, T, modified, stream);
+}
+
+int ftr_mutual_information_fwd_ws_f32(const float* px, const float* py, const int32_t* boundary, float* p,
+                                      size_t p_floats, int flags, float* ans, int B, int S, int T, int modified,
+                                      void* stream) {
+  return mi_fwd_common("mutual_information_fwd_ws", px, py, boundary, p, p_floats, flags, ans, B, S, T, modified, stream);
+}
+
+int ftr_mutual_information_bwd_ws_f32(const float* px, const float* py, const int32_t* boundary, const float* p,
+                                      size_t p_floats, int flags, float* p_grad, float* px_grad, float* py_grad,
+                                      float* ans_grad, int overwrite_ans_grad, int B, int S, int T, int modified,
+                                      void* stream) {
+  return mi_bwd_common("mutual_information_bwd_ws", px, py, boundary, p, p_floats, flags, p_grad, px_grad, py_grad, ans_grad,
+                       overwrite_ans_grad, B, S, T, modified, stream);
+}
+
+int ftr_mutual_information_workspace_init(float* p, size_t p_floats, int B, int S, int T, void* stream) {
   clear_error();
-  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_bwd: negative size B=%d S=%d T=%d", B, S, T);
-  if (B == 0) return FTR_OK;
-  FTR_REQUIRE(p && py_grad, "mutual_information_bwd: null p/py_grad");
-  FTR_REQUIRE(ans_grad || mi_impl() == 0, "mutual_information_bwd: ans_grad may be NULL (= ones) only with the default kernel family");
-  FTR_REQUIRE(px_grad || S == 0 || (modified && T == 0), "mutual_information_bwd: null px_grad");
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_workspace_init: negative size");
+  FTR_REQUIRE(p, "mutual_information_workspace_init: null workspace");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (mi_impl() == 1) {
-    FTR_REQUIRE((px || S == 0) && py, "mutual_information_bwd: the plain family needs px and py");
-    return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
-  }
-  return mi_bidir_bwd(boundary, p, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
+  return mi_bidir_ws_init(p, p_floats, B, S, T, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_mutual_information_status(const float* p, size_t p_floats, int B, int S, int T, int* status_host,
+                                  long long* dirty_words_host, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_status: negative size");
+  FTR_REQUIRE(p && status_host, "mutual_information_status: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return mi_bidir_status(p, p_floats, B, S, T, status_host, dirty_words_host, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, void* stream) {

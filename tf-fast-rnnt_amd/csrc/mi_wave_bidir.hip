@@ -27,8 +27,16 @@
 // (s - s_begin, t - t_begin); "REV addressing" = (s_end - s, t_end - t).  Forward alpha and flow beta use FWD,
 // forward beta and flow alpha use REV.
 //
-// Workspace ("p" in the C ABI), floats:  [ G_alpha lattice | G_beta lattice | pmid 2*B*(S+1) | occ B*(S+1) | pad |
-//                                          granules 2 * B * NB * Tg * 8 bytes ].
+// Workspace ("p" in the C ABI), floats:  [ G_alpha lattice | G_beta lattice | pmid 2*B*(S+1) | occ B*(S+1) | seed B | pad |
+//                                          ctrl: status word, done[B], uflags[B] | pad |
+//                                          granules of the forward launch 2*B*NB*Tg*8 bytes | granules of the flow launch ].
+// "ctrl + granules" is the HAND-OFF region: it must be all zero when a launch starts.  The launches leave it all zero
+// again (every consumer clears the granules it has imported, the last workgroup of an utterance clears its counters),
+// so a caller that initialised the workspace once (ftr_mutual_information_workspace_init) passes FTR_MI_WS_CLEAN and no
+// memset node is needed; without the flag the launchers zero the region themselves.
+//   status   sticky: bit 0 = a band gave up waiting for its producer (the results of that launch are poisoned)
+//   done[b]  bands of utterance b that have delivered their cut values (the last one runs the cut reduction)
+//   uflags[b] bit 1 = a NaN was read from px / py inside the boundary rectangle of utterance b  ->  ans[b] = NaN
 #include "ftr_common.h"
 #include "mi_wave_common.h"
 #include <type_traits>
@@ -51,7 +59,10 @@ namespace {
 #ifndef FTR_POLL_SLEEP
 #define FTR_POLL_SLEEP 2
 #endif
-constexpr int kMaxSpin = 400000; // polls of ~1 us before a band gives up (never reached unless a producer died)
+#ifndef FTR_MAX_SPIN
+#define FTR_MAX_SPIN 400000
+#endif
+constexpr int kMaxSpin = FTR_MAX_SPIN; // polls of ~1 us before a band gives up (never reached unless a producer died)
 typedef unsigned long long u64;
 
 // Diagnostic build (make STAMPS=1 [STAMP_BAND=n]): per-wave busy / barrier-wait ticks of the forward kernel's slots,
@@ -83,17 +94,29 @@ __host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
 __device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
   return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool comm_import(float* in_ring, const u64* gran_in, int m, int lane, u64 g) {
+__device__ __forceinline__ bool comm_import(float* in_ring, u64* gran_in, int m, int lane, u64 g, int* status) {
   const int idx = CH * m + (lane & (CH - 1));
   for (int spins = 0;; ++spins) {
     const bool ok = (unsigned)(g >> 32) == (unsigned)(m + 1);
     if (__all(ok)) break;                 // wave-uniform exit
-    if (spins >= kMaxSpin) return false;  // wave-uniform (spins is uniform)
+    if (spins >= kMaxSpin) {              // wave-uniform (spins is uniform): the producer never showed up
+      if (lane == 0) __hip_atomic_fetch_or(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky
+      return false;
+    }
     __builtin_amdgcn_s_sleep(FTR_POLL_SLEEP);
     g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (lane < CH) in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
+  if (lane < CH) {
+    in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
+    // this band is the only reader: leave the granule zero for the next launch on this workspace (self-cleaning)
+    __hip_atomic_store(gran_in + idx, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return true;
+}
+// values on the cut go to the last workgroup of the utterance (possibly on another XCD): write-through stores, read
+// back with agent-scope loads after the done[] counter says everybody has delivered
+__device__ __forceinline__ void pmid_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ f4 rev4(const f4 t) {
   f4 v;
@@ -121,7 +144,8 @@ __device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
 template <bool MOD, bool REVM>
 __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float* __restrict__ px,
                                                const float* __restrict__ py, const Bound bd, float* __restrict__ wsb,
-                                               u64* __restrict__ gran_b, float* __restrict__ pmid_b, int b, int w,
+                                               u64* __restrict__ gran_b, float* __restrict__ pmid_b,
+                                               int* __restrict__ status, int* __restrict__ uflag_b, int b, int w,
                                                int Tg, int S, int T, int jstop) {
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
@@ -143,13 +167,13 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   // global steps, is at local step jl.  A band whose rows all lie beyond the cut has nothing to compute.
   const int jl = jstop - SKEW * 64 * w;
   if (jl < 0) {
-    if (wid == 0 && 64 * w + lane < Sn) pmid_b[64 * w + lane] = kNeg;
+    if (wid == 0 && 64 * w + lane < Sn) pmid_store(pmid_b + 64 * w + lane, kNeg);
     return;
   }
   // A band never steps past its own last column (local step Tn - 1 + 63 * SKEW): if the cut lies beyond that, none
   // of the band's rows has a cell on the cut, but the band still feeds the bands below.
   const int nchunks_nat = (Tn + 63 * SKEW + CH - 1) / CH;
-  if (jl >= CH * nchunks_nat && wid == 0 && 64 * w + lane < Sn) pmid_b[64 * w + lane] = kNeg;
+  if (jl >= CH * nchunks_nat && wid == 0 && 64 * w + lane < Sn) pmid_store(pmid_b + 64 * w + lane, kNeg);
   const int klast = min(jl / CH + 1, nchunks_nat);   // chunks [0, klast): local steps 0 .. jl (and the rest of that chunk)
   const int klast_up = MOD ? klast : min((jl + 64) / CH + 1, nchunks_nat);   // what the band above computes (and publishes)
   const int nslots = klast + PRE + 1;
@@ -224,23 +248,29 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 
   if (wid == 2) {
     // ======================================================================= COMM wave
-    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;        // read by band w+1
-    const u64* gran_in = gran_b + (size_t)w * Tg;         // written by band w-1
-    const bool has_up = w > 0, has_down = w + 1 < NWact;
+    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;        // read (and cleared) by band w+1
+    u64* gran_in = gran_b + (size_t)w * Tg;               // written by band w-1
+    // publish only what will be imported (and cleared): the band below returns at once when all its rows lie beyond
+    // the cut (its jl = jl - 64 * SKEW is negative); otherwise it imports exactly the chunks [0, klast) published here
+    const bool has_up = w > 0, has_down = (w + 1 < NWact) && (jl - 64 * SKEW >= 0);
     bool dead = false;
     u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       if (kc - 1 >= 0 && kc - 1 < klast) {
         const float* tp = reinterpret_cast<const float*>(FTR_TP(kc - 1));
+#ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
+        if (has_down && lane < CH && !(w == 0 && !REVM)) {
+#else
         if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk kc-1 -> granules of the band below
+#endif
           const int m = kc - 1;
           const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
           const u64 g = ((u64)(unsigned)(m + 1) << 32) | (u64)__float_as_uint(v);
           __hip_atomic_store(gran_out + CH * m + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (kc - 1 == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
-          pmid_b[64 * w + lane] = tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)];
+          pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
       }
       const int m = kc + LOOK;
       u64 g_next = 0;
@@ -250,7 +280,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #else
       if (has_up && !dead && m >= 0 && m < klast_up) {
 #endif
-        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {   // producer never showed up: poison, stop polling
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur, status)) {   // producer never showed up: poison, stop polling
           dead = true;
           in_ring[lane] = __builtin_nanf("");
         }
@@ -333,6 +363,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   };
   // kk = chunk being parked.  The origin cell (chunk 0, tile row 0, quad 0, element 0 of band 0) gets Y := 0 so that
   // p = logadd(-inf, pcur(0) + 0) = 0 falls out of the recursion.
+  bool nan_seen = false;   // a NaN among the px / py values this lane staged (reported through uflags: ans = NaN)
   auto park = [&](int kk, const f4 (&x)[4], const f4 (&y)[4]) {
     f4* dX = FTR_TX(kk);
     f4* dY = FTR_TY(kk);
@@ -342,8 +373,10 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       f4 xs, ys;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        xs[e] = fmaxf(x[m][REVM ? 3 - e : e] * kLog2e, kNeg);  // log2 domain; -inf (and nan) -> kNeg; REV: swap
-        ys[e] = fmaxf(y[m][REVM ? 3 - e : e] * kLog2e, kNeg);
+        const float vx = x[m][REVM ? 3 - e : e] * kLog2e, vy = y[m][REVM ? 3 - e : e] * kLog2e;   // log2 domain; REV: swap
+        nan_seen = nan_seen || (vx != vx) || (vy != vy);
+        xs[e] = fmaxf(vx, kNeg);  // -inf -> kNeg (a NaN too: the chain stays finite, the utterance is flagged instead)
+        ys[e] = fmaxf(vy, kNeg);
       }
       if (m == 0 && kk == 0 && w == 0 && lane == 0) ys[0] = 0.0f;
       dX[fq * PLANE + row] = xs;
@@ -507,6 +540,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #pragma unroll
     for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
   }
+  if (__any(nan_seen) && lane == 0) __hip_atomic_fetch_or(uflag_b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   FTR_SYNC_REPORT(1);
 }
 
@@ -515,44 +549,18 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #undef FTR_TD
 #undef FTR_TP
 
-template <bool MOD>
-__global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
-    const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
-    float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, int B, int NB, int Tg, int S, int T) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int b2 = blockIdx.x % (2 * B);           // band-major block ids: producers are dispatched first
-  const int w = blockIdx.x / (2 * B);            // band of 64 walk rows
-  const int dir = b2 / B, b = b2 - dir * B;
-  const Bound bd = load_boundary(boundary, b, S, T);
-  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
-  if (Sn <= 0 || Tn <= 0) return;                // the mid kernel reports ans = 0
-  if (w >= ((Sn + 63) >> 6)) return;             // bands past the utterance's last row: nobody waits for them
-  const Cut cut = make_cut<MOD>(Sn, Tn);
-  const int T1 = MOD ? T : T + 1;
-  const float* pxb = px + (size_t)b * S * T1;
-  const float* pyb = py + (size_t)b * (S + 1) * T;
-  float* wsb = ws + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
-  u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
-  float* pmid_b = pmid + ((size_t)dir * B + b) * (S + 1);
-  if (dir == 0) bidir_fwd_body<MOD, false>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, b, w, Tg, S, T, cut.jm);
-  else bidir_fwd_body<MOD, true>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, b, w, Tg, S, T, cut.D - cut.jm);
+// ----------------------------------------------------------------------------------------------------- cut
+// The cut reduction, run by the last workgroup of an utterance to deliver its cut values (256 threads):
+// ans[b] = logsumexp over the cut of p + q (log2 domain in, natural log out); occ[b][s - s_begin] = the occupancy of the
+// cut cell in lattice row s.  Alpha lane r and beta lane Sn-1-r hold the same cell.  pa / pb were written with
+// write-through stores by workgroups anywhere on the chip: agent-scope loads.
+__device__ __forceinline__ float pmid_load(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// ----------------------------------------------------------------------------------------------------- mid
-// ans[b] = logsumexp over the cut of p + q (log2 domain in, natural log out); occ[b][s - s_begin] = the occupancy
-// of the cut cell in lattice row s.  Alpha lane r and beta lane Sn-1-r hold the same cell.
-__global__ __launch_bounds__(256) void mi_bidir_mid_kernel(const int32_t* __restrict__ boundary,
-                                                           const float* __restrict__ pmid, float* __restrict__ occ,
-                                                           float* __restrict__ ans, int B, int S, int T) {
-  __shared__ float red[4];
-  const int b = blockIdx.x;
-  const Bound bd = load_boundary(boundary, b, S, T);
-  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
-  if (Sn <= 0 || Tn <= 0) { if (threadIdx.x == 0) ans[b] = 0.0f; return; }
-  const float* pa = pmid + (size_t)b * (S + 1);
-  const float* pb = pmid + ((size_t)B + b) * (S + 1);
+__device__ __forceinline__ void cut_reduce(float* red, const float* __restrict__ pa, const float* __restrict__ pb,
+                                           float* __restrict__ ob, float* __restrict__ ans_b, int Sn, bool poisoned) {
   float m = -INFINITY;
-  for (int r = threadIdx.x; r < Sn; r += 256) m = fmaxf(m, pa[r] + pb[Sn - 1 - r]);
+  for (int r = threadIdx.x; r < Sn; r += 256) m = fmaxf(m, pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -560,20 +568,81 @@ __global__ __launch_bounds__(256) void mi_bidir_mid_kernel(const int32_t* __rest
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float sum = 0.0f;
-  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f(pa[r] + pb[Sn - 1 - r] - m);
+  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f(pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r) - m);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
   __syncthreads();
   sum = (red[0] + red[1]) + (red[2] + red[3]);
   const float total = m + log2f(sum);
-  const bool dead = !(total > kNegThresh);      // no path (or nan): ans = -inf, no flow
-  if (threadIdx.x == 0) ans[b] = dead ? -INFINITY : total * kLn2;
-  float* ob = occ + (size_t)b * (S + 1);
+  const bool dead = !(total > kNegThresh);      // no path: ans = -inf, no flow
+  // a NaN among the inputs of this utterance, or a band that gave up waiting: ans = NaN (loud), no flow
+  if (threadIdx.x == 0) *ans_b = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : total * kLn2);
   // normalised with the very sum they add up to (not with exp2(-total)): the injected occupancies sum to 1 to
   // rounding, whatever the magnitude of p + q (thousands on long utterances)
   const float inv = 1.0f / sum;
-  for (int r = threadIdx.x; r < Sn; r += 256) ob[r] = dead ? 0.0f : exp2f(pa[r] + pb[Sn - 1 - r] - m) * inv;
+  for (int r = threadIdx.x; r < Sn; r += 256)
+    ob[r] = (dead || poisoned) ? 0.0f : exp2f(pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r) - m) * inv;
+}
+
+struct Ctrl {           // int offsets into the ctrl block of the workspace
+  int* status; int* done; int* uflags;
+};
+__device__ __forceinline__ Ctrl ctrl_of(int* ctrl, int B) {
+  Ctrl c; c.status = ctrl; c.done = ctrl + 4; c.uflags = ctrl + 4 + B; return c;
+}
+
+template <bool MOD>
+__global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
+    const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
+    float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, float* __restrict__ occ,
+    int* __restrict__ ctrl, float* __restrict__ ans, int B, int NB, int Tg, int S, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // band-major block ids: producers (lower band index) have lower ids.  Forward progress of a band that waits for the
+  // band above relies on the dispatcher starting workgroups in id order (true on this hardware; an oversubscribed grid
+  // keeps working because a band only ever waits for lower ids); if that ever fails the wait is bounded (kMaxSpin) and
+  // sets the sticky status word.
+  const int b2 = blockIdx.x % (2 * B);
+  const int w = blockIdx.x / (2 * B);            // band of 64 walk rows
+  const int dir = b2 / B, b = b2 - dir * B;
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  if (Sn <= 0 || Tn <= 0) {                      // empty rectangle: ans = 0 (the reference never writes it)
+    if (dir == 0 && w == 0 && threadIdx.x == 0) ans[b] = 0.0f;
+    return;
+  }
+  const int NWact = (Sn + 63) >> 6;
+  if (w >= NWact) return;                        // bands past the utterance's last row: nobody waits for them
+  const Cut cut = make_cut<MOD>(Sn, Tn);
+  const int T1 = MOD ? T : T + 1;
+  const float* pxb = px + (size_t)b * S * T1;
+  const float* pyb = py + (size_t)b * (S + 1) * T;
+  float* wsb = ws + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
+  u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
+  float* pmid_b = pmid + ((size_t)dir * B + b) * (S + 1);
+  const Ctrl c = ctrl_of(ctrl, B);
+  if (dir == 0) bidir_fwd_body<MOD, false>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, b, w, Tg, S, T, cut.jm);
+  else bidir_fwd_body<MOD, true>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, b, w, Tg, S, T, cut.D - cut.jm);
+
+  // ---- the last of the 2 * NWact bands of this utterance to get here runs the cut reduction
+  __builtin_amdgcn_s_waitcnt(kVmcnt0);           // this wave's cut values / flags have left
+  __syncthreads();
+  int* sflag = reinterpret_cast<int*>(smem);
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(c.done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sflag[0] = (old == 2 * NWact - 1);
+  }
+  __syncthreads();
+  if (!sflag[0]) return;
+  const int uf = __hip_atomic_load(c.uflags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int stt = __hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {                        // counters back to zero for the next launch on this workspace
+    __hip_atomic_store(c.done + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c.uflags + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  cut_reduce(reinterpret_cast<float*>(smem) + 4, pmid + (size_t)b * (S + 1), pmid + ((size_t)B + b) * (S + 1),
+             occ + (size_t)b * (S + 1), ans + b, Sn, (uf | stt) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------- flow
@@ -588,7 +657,8 @@ template <bool MOD, bool REVM>
 __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound bd, const float* __restrict__ wsb,
                                                 u64* __restrict__ gran_b, const float* __restrict__ occ_b,
                                                 float* __restrict__ pxg, float* __restrict__ pyg,
-                                                float* __restrict__ ans_grad, int overwrite, int b, int w, int Tg,
+                                                const float* __restrict__ seed, float* __restrict__ check,
+                                                int* __restrict__ status, int b, int w, int Tg,
                                                 int S, int T, int jinj) {
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
@@ -636,7 +706,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     float inj = 0.0f;
     {
       const int r = 64 * w + lane;
-      if (r < Sn) inj = occ_b[REVM ? (Sn - 1 - r) : r] * (ans_grad ? ans_grad[b] : 1.0f);   // NULL ans_grad = ones
+      if (r < Sn) inj = occ_b[REVM ? (Sn - 1 - r) : r] * (seed ? seed[b] : 1.0f);   // NULL seed = ones
     }
     float yprev = 0.0f, xprev = 0.0f, ecarry = 0.0f;
 
@@ -870,25 +940,28 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     // this band's py_grad stores (the IO-out wave keeps the px_grad stores: two balanced store streams), and the
     // import of the band above's flow.  The stores are issued before the poll, so a late producer cannot delay them.
     u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
-    const u64* gran_in = gran_b + (size_t)w * Tg;
+    u64* gran_in = gran_b + (size_t)w * Tg;
     const bool has_up = w > 0, has_down = w + 1 < NWact;
+    // publish only what the band below imports (and clears): its loop visits the chunks from
+    // max(kfirst_up, its kfirst - PRE + LOOK) on, with its jli = jli - 64 * SKEW
+    const int kpub = max(kfirst, max(jli - 64 * SKEW, 0) / CH - PRE + LOOK);
     bool dead = false;
     u64 g_cur = 0;
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int k = kc - 1;
       if (k >= kfirst && k < nchunks) {
-        if (has_down && lane < CH) {
+        if (has_down && k >= kpub && lane < CH) {
           const float* txo = reinterpret_cast<const float*>(FTR_TXO(k));
           const float v = txo[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
           const u64 g = ((u64)(unsigned)(k + 1) << 32) | (u64)__float_as_uint(v);
           __hip_atomic_store(gran_out + CH * k + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (overwrite && ans_grad && k == (jfin >> 4) && lane == lfin) {   // p_grad at the origin = both inflows
+        if (check && k == (jfin >> 4) && lane == lfin) {   // p_grad at the origin = both inflows (the self check)
           const int idx = ((((jfin & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jfin & 3);
           float pg = reinterpret_cast<const float*>(FTR_TPX(k))[idx] + reinterpret_cast<const float*>(FTR_TPY(k))[idx];
-          if (jfin == jli) pg += occ_b[REVM ? (Sn - 1 - (64 * w + lane)) : (64 * w + lane)] * ans_grad[b];   // one-cell lattice
-          ans_grad[b] = pg;
+          if (jfin == jli) pg += occ_b[REVM ? (Sn - 1 - (64 * w + lane)) : (64 * w + lane)] * (seed ? seed[b] : 1.0f);   // one-cell lattice
+          check[b] = pg;
         }
         if (k >= K0d && k < K1) drain_fast(k, std::false_type{}, std::true_type{});   // wave-uniform
         else drain_general(k, std::false_type{}, std::true_type{});
@@ -897,7 +970,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       u64 g_next = 0;
       if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
       if (has_up && !dead && m >= kfirst_up && m < nchunks) {
-        if (!comm_import(in_ring, gran_in, m, lane, g_cur)) {
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur, status)) {
           dead = true;
           in_ring[lane] = __builtin_nanf("");
         }
@@ -972,7 +1045,7 @@ template <bool MOD>
 __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
     const int32_t* __restrict__ boundary, const float* __restrict__ ws, u64* __restrict__ gran,
     const float* __restrict__ occ, float* __restrict__ px_grad, float* __restrict__ py_grad,
-    float* __restrict__ ans_grad, int overwrite, int B, int NB, int Tg, int S, int T) {
+    const float* __restrict__ seed, float* __restrict__ check, int* __restrict__ ctrl, int B, int NB, int Tg, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NOFF = MOD ? 1 : 0;
   const int b2 = blockIdx.x % (2 * B);
@@ -1028,8 +1101,10 @@ __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
   const float* occ_b = occ + (size_t)b * (S + 1);
   // dir 0 holds the alpha ratios: its flow runs in REV addressing from the cut (walk step D - jm) to the origin;
   // dir 1 holds the beta ratios: its flow runs in FWD addressing from the cut (walk step jm) to the end cell.
-  if (dir == 0) bidir_flow_body<MOD, true>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, ans_grad, overwrite, b, w, Tg, S, T, cut.D - cut.jm);
-  else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, ans_grad, 0, b, w, Tg, S, T, cut.jm);
+  // `seed` (the incoming ans_grad, never written by this launch) and `check` (p_grad at the origin, written by the band
+  // that reaches it) are different buffers: no workgroup reads what another one writes
+  if (dir == 0) bidir_flow_body<MOD, true>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, check, ctrl, b, w, Tg, S, T, cut.D - cut.jm);
+  else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, nullptr, ctrl, b, w, Tg, S, T, cut.jm);
 }
 
 inline size_t bidir_lds_bytes() { return (size_t)8 * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }   // forward: 8 tiles + ring; flow: 6 tiles + 2 rings
@@ -1059,18 +1134,24 @@ inline int allow_big_lds(K kernel, const char* what) {
 
 struct BidirLayout {
   size_t lat;       // floats per ratio lattice (padded)
-  size_t pmid_off, occ_off, gran_off;   // float offsets
+  size_t pmid_off, occ_off, seed_off, ctrl_off, gran_off, total;   // float offsets
+  size_t ctrl_floats, gran_floats;                                   // ctrl block; ONE granule region (forward or flow)
   int NB, Tg;
 };
-inline BidirLayout bidir_layout(int B, int S, int T, int modified) {
+// sized for the regular variant (which needs more granules) whatever `modified` is, so that one workspace serves both
+inline BidirLayout bidir_layout(int B, int S, int T) {
   BidirLayout l;
   l.lat = lattice_floats(B, S, T);
   l.pmid_off = 2 * l.lat;
   l.occ_off = l.pmid_off + 2 * (size_t)B * (S + 1);
-  size_t g = l.occ_off + (size_t)B * (S + 1);
-  l.gran_off = (g + 3) & ~(size_t)3;
+  l.seed_off = l.occ_off + (size_t)B * (S + 1);
+  l.ctrl_off = (l.seed_off + (size_t)B + 3) & ~(size_t)3;
+  l.ctrl_floats = ((size_t)4 + 2 * (size_t)B + 3) & ~(size_t)3;     // status + pad, done[B], uflags[B]
+  l.gran_off = l.ctrl_off + l.ctrl_floats;
   l.NB = (S + 1 + 63) / 64;
-  l.Tg = granules_per_band(T, modified);
+  l.Tg = granules_per_band(T, 0);
+  l.gran_floats = 2 * (2 * (size_t)B * l.NB * l.Tg);                 // u64 granules, two directions
+  l.total = l.gran_off + 2 * l.gran_floats + 4;
   return l;
 }
 
@@ -1096,52 +1177,114 @@ __global__ void selftest_kernel(const float* __restrict__ in, float* __restrict_
 
 }  // namespace
 
-// floats of workspace the bidirectional kernels need in total (sized for the regular variant, which needs more)
-size_t mi_bidir_workspace_floats(int B, int S, int T) {
-  const BidirLayout l = bidir_layout(B, S, T, 0);
-  return l.gran_off + 2 * (2 * (size_t)B * l.NB * l.Tg) + 4;
+// floats of workspace the bidirectional kernels need in total
+size_t mi_bidir_workspace_floats(int B, int S, int T) { return bidir_layout(B, S, T).total; }
+
+namespace {
+int check_ws(const char* what, const float* ws, size_t ws_floats, const BidirLayout& l) {
+  if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) { set_error("%s: the workspace must be 16-byte aligned", what); return FTR_ERR_INVALID_ARG; }
+  if (ws_floats < l.total) {
+    set_error("%s: the workspace holds %zu floats, ftr_mutual_information_workspace_floats() asks for %zu (it is NOT the "
+              "reference's [B,S+1,T+1] temp)", what, ws_floats, l.total);
+    return FTR_ERR_INVALID_ARG;
+  }
+  return FTR_OK;
+}
+// zeroes the hand-off region (ctrl + both granule regions)
+int clear_handoff(const char* what, float* ws, const BidirLayout& l, hipStream_t st) {
+  if (hipMemsetAsync(ws + l.ctrl_off, 0, sizeof(float) * (l.total - l.ctrl_off), st) != hipSuccess) {
+    (void)hipGetLastError(); set_error("%s: memset of the hand-off region failed", what); return FTR_ERR_LAUNCH;
+  }
+  return FTR_OK;
+}
+}  // namespace
+
+int mi_bidir_ws_init(float* ws, size_t ws_floats, int B, int S, int T, hipStream_t st) {
+  const BidirLayout l = bidir_layout(B, S, T);
+  int rc = check_ws("mutual_information_workspace_init", ws, ws_floats, l);
+  if (rc != FTR_OK) return rc;
+  return clear_handoff("mutual_information_workspace_init", ws, l, st);
 }
 
-int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, float* ans, int B, int S,
-                 int T, int modified, hipStream_t st) {
-  const BidirLayout l = bidir_layout(B, S, T, modified);
+int mi_bidir_status(const float* ws, size_t ws_floats, int B, int S, int T, int* status_host, long long* dirty_host,
+                    hipStream_t st) {
+  const BidirLayout l = bidir_layout(B, S, T);
+  int rc = check_ws("mutual_information_status", ws, ws_floats, l);
+  if (rc != FTR_OK) return rc;
+  if (hipMemcpyAsync(status_host, ws + l.ctrl_off, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    (void)hipGetLastError(); set_error("mutual_information_status: copy failed"); return FTR_ERR_LAUNCH;
+  }
+  if (dirty_host) {   // diagnostic: non-zero words of the hand-off region apart from the status word (must be 0 between launches)
+    const size_t n = l.total - l.ctrl_off;
+    unsigned* h = static_cast<unsigned*>(malloc(n * sizeof(unsigned)));
+    if (!h || hipMemcpyAsync(h, ws + l.ctrl_off, n * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      free(h); (void)hipGetLastError(); set_error("mutual_information_status: copy failed"); return FTR_ERR_LAUNCH;
+    }
+    long long cnt = 0;
+    for (size_t i = 1; i < n; ++i) cnt += (h[i] != 0);
+    free(h);
+    *dirty_host = cnt;
+  }
+  return FTR_OK;
+}
+
+int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, size_t ws_floats, int flags,
+                 float* ans, int B, int S, int T, int modified, hipStream_t st) {
+  const BidirLayout l = bidir_layout(B, S, T);
+  int rc = check_ws("mutual_information_fwd", ws, ws_floats, l);
+  if (rc != FTR_OK) return rc;
+  if (!(flags & FTR_MI_WS_CLEAN)) { rc = clear_handoff("mutual_information_fwd", ws, l, st); if (rc != FTR_OK) return rc; }
   u64* gran = reinterpret_cast<u64*>(ws + l.gran_off);
-  if ((reinterpret_cast<uintptr_t>(gran) & 7) != 0) { set_error("mi_bidir_fwd: workspace must be 16-byte aligned"); return FTR_ERR_INVALID_ARG; }
-  if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_fwd: memset failed"); return FTR_ERR_LAUNCH; }
+  int* ctrl = reinterpret_cast<int*>(ws + l.ctrl_off);
   const dim3 grid(2 * B * l.NB);
   const size_t lds = spread_lds(bidir_lds_bytes(), (int)grid.x);
   static bool big_ok = false;
   if (!big_ok) {
-    int rc = allow_big_lds(mi_bidir_fwd_kernel<true>, "mi_bidir_fwd");
+    rc = allow_big_lds(mi_bidir_fwd_kernel<true>, "mi_bidir_fwd");
     if (rc == FTR_OK) rc = allow_big_lds(mi_bidir_fwd_kernel<false>, "mi_bidir_fwd");
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, B, l.NB, l.Tg, S, T);
-  int rc = check_launch("mi_bidir_fwd");
-  if (rc != FTR_OK) return rc;
-  hipLaunchKernelGGL(mi_bidir_mid_kernel, dim3(B), dim3(256), 0, st, boundary, ws + l.pmid_off, ws + l.occ_off, ans, B, S, T);
-  return check_launch("mi_bidir_mid");
+  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ctrl, ans, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ctrl, ans, B, l.NB, l.Tg, S, T);
+  return check_launch("mi_bidir_fwd");
 }
 
-int mi_bidir_bwd(const int32_t* boundary, const float* ws, float* px_grad, float* py_grad, float* ans_grad,
-                 int overwrite, int B, int S, int T, int modified, hipStream_t st) {
-  const BidirLayout l = bidir_layout(B, S, T, modified);
-  float* wsm = const_cast<float*>(ws);   // the granule tail of the workspace is scratch
-  u64* gran = reinterpret_cast<u64*>(wsm + l.gran_off);
-  if (hipMemsetAsync(gran, 0, sizeof(u64) * 2 * (size_t)B * l.NB * l.Tg, st) != hipSuccess) { set_error("mi_bidir_bwd: memset failed"); return FTR_ERR_LAUNCH; }
+int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int flags, float* px_grad, float* py_grad,
+                 float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st) {
+  const BidirLayout l = bidir_layout(B, S, T);
+  int rc = check_ws("mutual_information_bwd", ws, ws_floats, l);
+  if (rc != FTR_OK) return rc;
+  float* wsm = const_cast<float*>(ws);   // seed snapshot, ctrl and the flow granules are scratch
+  // no memset here: the forward launch of this workspace zeroed (or found clean) the whole hand-off region, and has
+  // left ctrl and its own granule region clean again; the flow launch uses its own granule region
+  (void)flags;
+  u64* gran = reinterpret_cast<u64*>(wsm + l.gran_off + l.gran_floats);
+  // the seed is read by every workgroup of an utterance and the self check is written by one of them: the launch reads
+  // a snapshot so that it never reads what it writes
+  const float* seed = ans_grad;
+  float* check = nullptr;
+  if (ans_grad && overwrite) {
+    if (hipMemcpyAsync(wsm + l.seed_off, ans_grad, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      (void)hipGetLastError(); set_error("mi_bidir_bwd: seed snapshot failed"); return FTR_ERR_LAUNCH;
+    }
+    seed = wsm + l.seed_off;
+    check = ans_grad;
+  }
+  int* ctrl = reinterpret_cast<int*>(wsm + l.ctrl_off);
   const dim3 grid(2 * B * l.NB);
   const size_t lds = spread_lds(bidir_lds_bytes(), (int)grid.x);
   static bool big_ok = false;
   if (!big_ok) {
-    int rc = allow_big_lds(mi_bidir_flow_kernel<true>, "mi_bidir_bwd");
+    rc = allow_big_lds(mi_bidir_flow_kernel<true>, "mi_bidir_bwd");
     if (rc == FTR_OK) rc = allow_big_lds(mi_bidir_flow_kernel<false>, "mi_bidir_bwd");
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, ans_grad, overwrite, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
 }
 

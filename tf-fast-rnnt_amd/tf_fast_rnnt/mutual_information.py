@@ -50,6 +50,37 @@ def _as_boundary(boundary, B: int, device) -> Optional[torch.Tensor]:
     return boundary.contiguous()
 
 
+class _Workspace:
+    """One cached fwd->bwd workspace per (device, stream, B, S, T): allocated and initialised
+    (ftr_mutual_information_workspace_init) once, then handed to every launch with FTR_MI_WS_CLEAN -- the launches leave
+    the hand-off region clean, so no memset node is needed.  Safe because every user of the workspace in this package
+    runs the forward and the backward launch back to back on one stream (the occupancies, not the workspace, are what
+    autograd keeps).  Under stream capture the cache is bypassed (a graph owns its allocations)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, L, device, B, S, T):
+        st = torch.cuda.current_stream(device)
+        if torch.cuda.is_current_stream_capturing():
+            n = L.ftr_mutual_information_workspace_floats(B, S, T)
+            return torch.empty(n, dtype=torch.float32, device=device), n, 0
+        key = (device.index, st.cuda_stream, B, S, T)
+        hit = cls._cache.get(key)
+        if hit is None:
+            if len(cls._cache) >= 8:           # a training loop has a handful of shapes; do not hoard HBM beyond that
+                cls._cache.pop(next(iter(cls._cache)))
+            n = L.ftr_mutual_information_workspace_floats(B, S, T)
+            ws = torch.empty(n, dtype=torch.float32, device=device)
+            _lib.call("ftr_mutual_information_workspace_init", ws.data_ptr(), n, B, S, T, st.cuda_stream)
+            hit = cls._cache[key] = (ws, n)
+        return hit[0], hit[1], _lib.FTR_MI_WS_CLEAN
+
+
+def clear_workspace_cache() -> None:
+    """Drops the cached recursion workspaces (they are re-created on demand)."""
+    _Workspace._cache.clear()
+
+
 def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[torch.Tensor],
                         need_grads: bool, ans_grad: Optional[torch.Tensor] = None,
                         return_ans_grad_check: bool = False, ans_grad_is_one: bool = False):
@@ -71,10 +102,10 @@ def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[t
     L = _lib.lib()
     with torch.cuda.device(px.device):
         st = _stream_ptr(px)
-        ws = torch.empty(L.ftr_mutual_information_workspace_floats(B, S, T), dtype=torch.float32, device=px.device)
+        ws, ws_floats, flags = _Workspace.get(L, px.device, B, S, T)
         ans = torch.empty((B,), dtype=torch.float32, device=px.device)
-        _lib.call("ftr_mutual_information_fwd_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), _ptr(ans),
-                                                    B, S, T, modified, st)
+        _lib.call("ftr_mutual_information_fwd_ws_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), ws_floats, flags,
+                                                       _ptr(ans), B, S, T, modified, st)
         if not need_grads:
             return (ans, None, None, None) if return_ans_grad_check else (ans, None, None)
         px_grad = torch.empty_like(px)
@@ -89,8 +120,9 @@ def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[t
         p_grad = None
         if L.ftr_get_mi_impl() == 1:   # the plain family follows the reference and materialises p_grad
             p_grad = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=px.device)
-        _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), _ptr(p_grad),
-                                                    _ptr(px_grad), _ptr(py_grad), _ptr(ag), overwrite, B, S, T, modified, st)
+        _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), ws_floats, flags,
+                                                       _ptr(p_grad), _ptr(px_grad), _ptr(py_grad), _ptr(ag), overwrite,
+                                                       B, S, T, modified, st)
     return (ans, px_grad, py_grad, ag) if return_ans_grad_check else (ans, px_grad, py_grad)
 
 

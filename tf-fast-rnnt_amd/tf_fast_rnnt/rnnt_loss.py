@@ -113,7 +113,7 @@ class _SimpleLoss(torch.autograd.Function):
     the fly (ftr_simple_logprobs_bwd_*_scaled_f32) -- no framework-side pass over a lattice anywhere."""
 
     @staticmethod
-    def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, delay_penalty, code):
+    def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, delay_penalty, code, want_occupancies):
         B, T, C = am.shape
         S = lm.shape[1] - 1
         T1 = T if modified else T + 1
@@ -132,11 +132,17 @@ class _SimpleLoss(torch.autograd.Function):
             _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
                       _ptr(lm_max), _ptr(boundary), int(termination_symbol), float(delay_penalty), _ptr(px), _ptr(py),
                       B, T, S, C, int(modified), st)
-        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, True, ans_grad_is_one=True)
+        # the recursion backward (occupancies) only when somebody wants them: the caller (calc_gradients) or autograd
+        need = bool(want_occupancies) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
         del px, py
         loss = _negated_reduce_native(ans, code)
-        ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0),
-                              px_grad, py_grad)
+        if need:
+            ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0),
+                                  px_grad, py_grad)
+        else:
+            px_grad = torch.zeros((B, S, T1), dtype=torch.float32, device=dev)
+            py_grad = torch.zeros((B, S + 1, T), dtype=torch.float32, device=dev)
         ctx.has_boundary = boundary is not None
         ctx.meta = (int(termination_symbol), int(modified), int(code))
         ctx.mark_non_differentiable(px_grad, py_grad)
@@ -167,7 +173,7 @@ class _SimpleLoss(torch.autograd.Function):
                       modified, st)
             _lib.call("ftr_simple_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx), _ptr(rsy),
                       blank, _ptr(d_lm), B, S, C, st)
-        return d_lm, d_am, None, None, None, None, None, None
+        return d_lm, d_am, None, None, None, None, None, None, None
 
 
 def _check_simple_inputs(lm, am, symbols, termination_symbol):
@@ -301,7 +307,7 @@ def rnnt_loss_simple(
     symbols_i = _check_simple_inputs(lm, am, symbols, termination_symbol)
     pen = float(delay_penalty) if delay_penalty > 0.0 else 0.0
     loss, px_grad, py_grad = _SimpleLoss.apply(lm, am, symbols_i, termination_symbol, boundary, rnnt_type != "regular",
-                                               pen, code)
+                                               pen, code, bool(calc_gradients))
     return (loss, (px_grad, py_grad)) if calc_gradients else loss
 
 
