@@ -286,6 +286,11 @@ int ftr_selftest(void* scratch_dev, void* stream);
  * steady-state slot ([0..5] forward, [8..13] backward: compute, refill tile, issue stores, issue loads,
  * barrier, slots counted).  Synchronises the device. */
 int ftr_debug_stamps(unsigned long long* out16);
+/* Diagnostic: copies n <= 1024 words of the kernel timeline out of the library (host pointer) and re-arms it.  All zero
+ * unless the library was built with -DFTR_TRACE=1 (forward) or =2 (flow): [0] earliest workgroup start, [1] latest
+ * workgroup end, [2]/[3] start/end of one traced workgroup, [4] slots recorded, [16+k] its slot times, in 100 MHz ticks.
+ * Synchronises the device. */
+int ftr_debug_trace(unsigned long long* out, int n);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import tf_fast_rnnt as ft
 from tf_fast_rnnt import _lib
 from tf_fast_rnnt.mutual_information import _ptr
 
-def run(B, S, T, iters=20, impl=0, cold=False):
+def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
     dev = torch.device("cuda:0")
     L = _lib.lib()
     L.ftr_set_mi_impl(impl)
@@ -28,7 +28,7 @@ def run(B, S, T, iters=20, impl=0, cold=False):
     st = torch.cuda.current_stream().cuda_stream
     flush = torch.empty(512 * 1024 * 1024 // 4, device=dev) if cold else None
     tf = tb = 0.0
-    for i in range(iters + 3):
+    for i in range(iters + warm):
         if cold: flush.fill_(1.0)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
@@ -43,7 +43,7 @@ def run(B, S, T, iters=20, impl=0, cold=False):
             _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(pg), _ptr(gx), _ptr(gy), _ptr(ag), 1, B, S, T, 0, st)
         e[2].record()
         torch.cuda.synchronize()
-        if i >= 3:
+        if i >= warm:
             tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
     L.ftr_set_mi_impl(0)
     cells = B * (S + 1) * (T + 1)

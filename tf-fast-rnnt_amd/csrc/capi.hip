@@ -447,4 +447,12 @@ int ftr_debug_stamps(unsigned long long* out16) {
   return debug_stamps(out16);
 }
 
+int ftr_debug_trace(unsigned long long* out, int n) {
+  clear_error();
+  FTR_REQUIRE(out || n == 0, "debug_trace: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return debug_trace(out, n);
+}
+
 }  // extern "C"

@@ -108,4 +108,5 @@ int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32
 int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);
 int selftest(hipStream_t st, int* result_dev);
 int debug_stamps(unsigned long long* out16);
+int debug_trace(unsigned long long* out, int n);
 }

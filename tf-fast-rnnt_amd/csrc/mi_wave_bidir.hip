@@ -54,7 +54,7 @@ namespace {
 #define FTR_NPF_FWD 4
 #endif
 #ifndef FTR_NPF_FLOW
-#define FTR_NPF_FLOW 3
+#define FTR_NPF_FLOW 4
 #endif
 #ifndef FTR_POLL_SLEEP
 #define FTR_POLL_SLEEP 2
@@ -134,10 +134,15 @@ __device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
   return c;
 }
 
-#define FTR_TX(k) (lds + ((k) & 1) * TILE_F4)
-#define FTR_TY(k) (lds + (2 + ((k) & 1)) * TILE_F4)
-#define FTR_TD(k) (lds + (4 + ((k) & 1)) * TILE_F4)
-#define FTR_TP(k) (lds + (6 + ((k) & 1)) * TILE_F4)
+// input tiles: 3 buffers (chunk k+2 is being parked while chunk k+1 is read into registers and chunk k is computed from
+// registers); output tiles: 2 buffers (chunk k is written while chunk k-1 is drained).  (k) + 3 keeps the index
+// non-negative for the warm-up slots.
+#define FTR_TX(k) (lds + (((k) + 3) % 3) * TILE_F4)
+#define FTR_TY(k) (lds + (3 + ((k) + 3) % 3) * TILE_F4)
+#define FTR_TD(k) (lds + (6 + ((k) & 1)) * TILE_F4)
+#define FTR_TP(k) (lds + (8 + ((k) & 1)) * TILE_F4)
+constexpr int kFwdTiles = 10;
+constexpr int kAhead = 2;   // the IO-in wave parks chunk kc + kAhead during slot kc
 
 // ------------------------------------------------------------------------------------------------- forward
 // One direction of one band.  REVM selects the IO waves' addressing (see the header).
@@ -150,8 +155,11 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
   constexpr int NPF = FTR_NPF_FWD;
-  constexpr int LOOK = MOD ? 1 : 5;  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK
-  constexpr int PRE = NPF + 1;       // IO pipeline warm-up slots in front of chunk 0
+  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK: the compute wave reads it from the ring during
+  // slot kc + 1 (into registers) and uses it in slot kc + 2 for its chunk kc + 2, which needs the upper chunk kc + 2 + 4
+  // (regular: lane 0's neighbour is 63 steps ahead, plus one carried element) / kc + 2 (modified)
+  constexpr int LOOK = MOD ? 2 : 6;
+  constexpr int PRE = NPF + kAhead;  // IO pipeline warm-up slots in front of chunk 0
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
   const int T1 = MOD ? T : T + 1;
@@ -159,7 +167,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   const int NWact = (Sn + 63) >> 6;
 
   f4* lds = reinterpret_cast<f4*>(smem);
-  float* in_ring = reinterpret_cast<float*>(lds + 8 * TILE_F4);   // values of the band above (row row0-1)
+  float* in_ring = reinterpret_cast<float*>(lds + kFwdTiles * TILE_F4);   // values of the band above (row row0-1)
   for (int i = threadIdx.x; i < RINGN; i += blockDim.x) in_ring[i] = kNeg;
   __syncthreads();
 
@@ -193,22 +201,27 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     // to the arithmetic alone: both per-cell outputs -- copysign(e, d) for the IO-out wave and p itself for the COMM
     // wave (hand-off to the band below, values on the cut) -- leave through LDS tiles with two unconditional
     // ds_write_b128 per four steps; no exec masking, no selects, no global stores in this loop.
-    auto compute_chunk = [&](int k) {
+    // The operands of a whole chunk live in registers: they are read from the tiles (12 ds_read_b128, no wait in
+    // between) one slot ahead, while the previous chunk is computed, so that the dependent chain below never waits for
+    // the LDS (measured: with the reads issued one quad ahead, behind that quad's tile writes in the in-order LDS queue,
+    // every quad paid a full LDS round trip -- 1529 of the slot's 1729 cycles were this wave, profiles/r02_b_stamps_stage1.log).
+    struct Ops { f4 X[NQ], Y[NQ], E[NQ]; };
+    auto fetch = [&](int k, Ops& o) {
       const f4* cX = FTR_TX(k);
       const f4* cY = FTR_TY(k);
-      f4* cD = FTR_TD(k);
-      f4* cP = FTR_TP(k);
-      f4 Xn = cX[lane], Yn = cY[lane];
-      f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int j0 = CH * k + 4 * q;
-        const f4 X4 = Xn, Y4 = Yn, E4 = En;
-        if (q + 1 < NQ) {  // next quad's operands are fetched while this quad's chain runs
-          Xn = cX[(q + 1) * PLANE + lane];
-          Yn = cY[(q + 1) * PLANE + lane];
-          En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
-        }
+        o.X[q] = cX[q * PLANE + lane];
+        o.Y[q] = cY[q * PLANE + lane];
+        o.E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
+      }
+    };
+    auto compute_chunk = [&](int k, const Ops& o) {
+      f4* cD = FTR_TD(k);
+      f4* cP = FTR_TP(k);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f4 X4 = o.X[q], Y4 = o.Y[q], E4 = o.E[q];
         f4 XE;
         XE[0] = __builtin_fmaf(lane0, ecarry, X4[0]); XE[1] = __builtin_fmaf(lane0, E4[0], X4[1]);
         XE[2] = __builtin_fmaf(lane0, E4[1], X4[2]);  XE[3] = __builtin_fmaf(lane0, E4[2], X4[3]);
@@ -232,15 +245,32 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       }
     };
 
-    for (int gg = 0; gg < NIT * NPF; ++gg) {
-      const int kc = base + gg;
+    // slot kc: fetch chunk kc + 1 (parked during slot kc - 1), compute chunk kc from the registers fetched during
+    // slot kc - 1.  Two register sets, the loop is unrolled by two so that they swap roles without copies.
+    Ops oa, ob;
+    float ecarry0 = kNeg;
+    auto slot = [&](int kc, const Ops& cur, Ops& nxt) {
+      if (kc + 1 >= 0 && kc + 1 < klast) {
+        fetch(kc + 1, nxt);
+        // the element in front of chunk 0's first ring value: the band above's step 63 (regular; imported with its
+        // chunk 3 by now), nothing (modified: the ring still holds its initial -inf there)
+        if (kc + 1 == 0) ecarry0 = in_ring[RINGN - 1];
+      }
       if (kc >= 0 && kc < klast) {
-        if (kc == 0) ecarry = in_ring[RINGN - 1];
+        if (kc == 0) ecarry = ecarry0;
 #ifndef FTR_EXP_NOCOMPUTE
-        compute_chunk(kc);
+        compute_chunk(kc, cur);
 #endif
       }
       FTR_SYNC();
+#if defined(FTR_TRACE) && FTR_TRACE == 1
+      if (b == 0 && REVM == (FTR_TRACE_DIR != 0) && w == FTR_STAMP_BAND && lane == 0 && 16 + (kc - base) < kTraceN) { g_trace[16 + (kc - base)] = trace_now(); g_trace[4] = kc - base + 1; }
+#endif
+    };
+    static_assert((NPF & 1) == 0, "the slot loop is unrolled by two");
+    for (int gg = 0; gg < NIT * NPF; gg += 2) {
+      slot(base + gg, oa, ob);
+      slot(base + gg + 1, ob, oa);
     }
     FTR_SYNC_REPORT(0);
     return;
@@ -489,7 +519,11 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   };
 
   const int K0 = MOD ? 1 : 4;                                      // 16k - 63*SKEW >= 1
+#ifdef FTR_EXP_ALLGENERIC
+  const int K1 = 0;
+#else
   const int K1 = min((Tn >= CH) ? (Tn - CH) / CH + 1 : 0, klast);  // 16k + 15 < Tn
+#endif
 
   if (wid == 3) {
     // ------------------------------------------------------------------------- IO-out
@@ -507,18 +541,18 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 
   // --------------------------------------------------------------------------- IO-in
   auto slot_general = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    if (kc + 1 >= 0 && kc + 1 < klast) park(kc + 1, x, y);
-    if (kc + 1 + NPF >= 0 && kc + 1 + NPF < klast) load_general(kc + 1 + NPF, x, y);
+    if (kc + kAhead >= 0 && kc + kAhead < klast) park(kc + kAhead, x, y);
+    if (kc + kAhead + NPF >= 0 && kc + kAhead + NPF < klast) load_general(kc + kAhead + NPF, x, y);
     FTR_SYNC();
   };
   auto slot_fast = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    park(kc + 1, x, y);         // loads of chunk kc+1 were issued NPF slots ago
-    load_fast(kc + 1 + NPF, x, y);
+    park(kc + kAhead, x, y);         // loads of chunk kc+kAhead were issued NPF slots ago
+    load_fast(kc + kAhead + NPF, x, y);
     FTR_SYNC();
   };
 
-  // Fast slot kc: the loaded chunk kc+1+NPF is interior and inside [0, klast), the parked chunk kc+1 exists.
-  const int KF0 = max(K0 - 1 - NPF, -1), KF1 = (Sn >= 2) ? K1 - 1 - NPF : 0;      // fast slots: KF0 <= kc < KF1
+  // Fast slot kc: the loaded chunk kc+kAhead+NPF is interior and inside [0, klast), the parked chunk kc+kAhead exists.
+  const int KF0 = max(K0 - kAhead - NPF, -kAhead), KF1 = (Sn >= 2) ? K1 - kAhead - NPF : 0;      // fast slots: KF0 <= kc < KF1
   int it1 = (KF0 - base + NPF - 1) / NPF;                // first iteration whose first slot has kc >= KF0
   int it2 = (KF1 - base) / NPF;                          // first iteration whose last slot has kc >= KF1
   it1 = min(max(it1, 0), NIT);
@@ -605,6 +639,9 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   const int b2 = blockIdx.x % (2 * B);
   const int w = blockIdx.x / (2 * B);            // band of 64 walk rows
   const int dir = b2 / B, b = b2 - dir * B;
+#if defined(FTR_TRACE) && FTR_TRACE == 1
+  if (threadIdx.x == 0) { const u64 t = trace_now(); atomicMin(&g_trace[0], t); if (b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[2] = t; }
+#endif
   const Bound bd = load_boundary(boundary, b, S, T);
   const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
   if (Sn <= 0 || Tn <= 0) {                      // empty rectangle: ans = 0 (the reference never writes it)
@@ -627,6 +664,9 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   // ---- the last of the 2 * NWact bands of this utterance to get here runs the cut reduction
   __builtin_amdgcn_s_waitcnt(kVmcnt0);           // this wave's cut values / flags have left
   __syncthreads();
+#if defined(FTR_TRACE) && FTR_TRACE == 1
+  if (threadIdx.x == 0) { const u64 t = trace_now(); atomicMax(&g_trace[1], t); if (b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[3] = t; }
+#endif
   int* sflag = reinterpret_cast<int*>(smem);
   if (threadIdx.x == 0) {
     const int old = __hip_atomic_fetch_add(c.done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -646,10 +686,12 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------- flow
-#define FTR_TG(k) (lds + ((k) & 1) * TILE_F4)
-#define FTR_TPX(k) (lds + (2 + ((k) & 1)) * TILE_F4)
-#define FTR_TPY(k) (lds + (4 + ((k) & 1)) * TILE_F4)
-#define FTR_TXO(k) (lds + (6 + ((k) & 1)) * TILE_F4)
+#define FTR_TG(k) (lds + (((k) + 3) % 3) * TILE_F4)           // 3 input buffers, see the forward body
+#define FTR_TPX(k) (lds + (3 + ((k) & 1)) * TILE_F4)
+#define FTR_TPY(k) (lds + (5 + ((k) & 1)) * TILE_F4)
+#define FTR_TXO(k) (lds + (7 + ((k) & 1)) * TILE_F4)
+constexpr int kFlowTiles = 9;
+static_assert(kFlowTiles <= kFwdTiles, "bidir_lds_bytes() is sized for the forward kernel");
 
 // One direction of one band of the backward pass.  REVM = true: from the cut back to the origin (alpha half),
 // REVM = false: from the cut forward to the end cell (beta half).  jinj = walk step of the cut in this direction.
@@ -663,8 +705,8 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
   constexpr int NPF = FTR_NPF_FLOW;
-  constexpr int LOOK = MOD ? 1 : 5;
-  constexpr int PRE = NPF + 1;
+  constexpr int LOOK = MOD ? 2 : 6;      // see the forward body
+  constexpr int PRE = NPF + kAhead;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
   const int T1 = MOD ? T : T + 1;
@@ -672,7 +714,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   const int NWact = (Sn + 63) >> 6;
 
   f4* lds = reinterpret_cast<f4*>(smem);
-  float* in_ring = reinterpret_cast<float*>(lds + 8 * TILE_F4);   // tiles: G, PX, PY, XO (two of each)
+  float* in_ring = reinterpret_cast<float*>(lds + kFlowTiles * TILE_F4);   // tiles: G (three), PX, PY, XO (two of each)
   for (int i = threadIdx.x; i < RINGN; i += blockDim.x) in_ring[i] = 0.0f;
   __syncthreads();
 
@@ -710,22 +752,25 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     }
     float yprev = 0.0f, xprev = 0.0f, ecarry = 0.0f;
 
-    auto compute_chunk = [&](int k, auto inject_tag) {
-      constexpr bool INJ = decltype(inject_tag)::value;
+    // operands of a whole chunk in registers, fetched one slot ahead (see the forward body)
+    struct Ops { f4 G[NQ], E[NQ]; };
+    auto fetch = [&](int k, Ops& o) {
       const f4* cG = FTR_TG(k);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        o.G[q] = cG[q * PLANE + lane];
+        o.E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];
+      }
+    };
+    auto compute_chunk = [&](int k, const Ops& o, auto inject_tag) {
+      constexpr bool INJ = decltype(inject_tag)::value;
       f4* cPX = FTR_TPX(k);
       f4* cPY = FTR_TPY(k);
       f4* cXO = FTR_TXO(k);
-      f4 Gn = cG[lane];
-      f4 En = ring_in[((CH * k) & (RINGN - 1)) >> 2];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int j0 = CH * k + 4 * q;
-        const f4 G4 = Gn, E4 = En;
-        if (q + 1 < NQ) {
-          Gn = cG[(q + 1) * PLANE + lane];
-          En = ring_in[((j0 + 4) & (RINGN - 1)) >> 2];
-        }
+        const f4 G4 = o.G[q], E4 = o.E[q];
         f4 XO4, PX4, PY4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -749,19 +794,32 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       }
     };
 
-    for (int gg = 0; gg < NIT * NPF; ++gg) {
-      const int kc = base + gg;
+    Ops oa, ob;
+    float ecarry0 = 0.0f;
+    auto slot = [&](int kc, const Ops& cur, Ops& nxt) {
+      if (kc + 1 >= kfirst && kc + 1 < nchunks) {
+        fetch(kc + 1, nxt);
+        if (kc + 1 == kfirst) ecarry0 = in_ring[(CH * kfirst - 1) & (RINGN - 1)];   // the element in front of the first chunk
+      }
 #ifndef FTR_EXP_FLOW_NOCOMPUTE
       if (kc >= kfirst && kc < nchunks) {
         if (kc == kfirst) {
-          ecarry = in_ring[(CH * kfirst - 1) & (RINGN - 1)];
-          compute_chunk(kc, std::true_type{});
+          ecarry = ecarry0;
+          compute_chunk(kc, cur, std::true_type{});
         } else {
-          compute_chunk(kc, std::false_type{});
+          compute_chunk(kc, cur, std::false_type{});
         }
       }
 #endif
       FTR_FSYNC();
+#if defined(FTR_TRACE) && FTR_TRACE == 2
+      if (b == 0 && REVM == (FTR_TRACE_DIR == 0) && w == FTR_STAMP_BAND && lane == 0 && 16 + (kc - base) < kTraceN) { g_trace[16 + (kc - base)] = trace_now(); g_trace[4] = kc - base + 1; }
+#endif
+    };
+    static_assert((NPF & 1) == 0, "the slot loop is unrolled by two");
+    for (int gg = 0; gg < NIT * NPF; gg += 2) {
+      slot(base + gg, oa, ob);
+      slot(base + gg + 1, ob, oa);
     }
     FTR_FREPORT(0);
     return;
@@ -930,7 +988,11 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   };
 
   const int K0 = max(MOD ? 1 : 4, kfirst);
+#ifdef FTR_EXP_ALLGENERIC
+  const int K1 = 0;
+#else
   const int K1 = (Tn >= CH) ? (Tn - CH) / CH + 1 : 0;
+#endif
 
   const int K0d = max(MOD ? 1 : 4, kfirst + 1);     // the cut's chunk is drained with the per-step mask
 
@@ -998,18 +1060,18 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 
   // --------------------------------------------------------------------------- IO-in
   auto slot_general = [&](int kc, f4 (&gq)[4]) {
-    if (kc + 1 >= kfirst && kc + 1 < nchunks) park(kc + 1, gq);
-    if (kc + 1 + NPF >= kfirst && kc + 1 + NPF < nchunks) load_general(kc + 1 + NPF, gq);
+    if (kc + kAhead >= kfirst && kc + kAhead < nchunks) park(kc + kAhead, gq);
+    if (kc + kAhead + NPF >= kfirst && kc + kAhead + NPF < nchunks) load_general(kc + kAhead + NPF, gq);
     FTR_FSYNC();
   };
   auto slot_fast = [&](int kc, f4 (&gq)[4]) {
-    park(kc + 1, gq);
-    load_fast(kc + 1 + NPF, gq);
+    park(kc + kAhead, gq);
+    load_fast(kc + kAhead + NPF, gq);
     FTR_FSYNC();
   };
 
-  // fast slot kc: loaded chunk kc+1+NPF interior (and not before the cut's chunk), parked chunk kc+1 exists
-  const int KF0 = max(K0 - 1 - NPF, kfirst - 1), KF1 = K1 - 1 - NPF;
+  // fast slot kc: loaded chunk kc+kAhead+NPF interior (and not before the cut's chunk), parked chunk kc+kAhead exists
+  const int KF0 = max(K0 - kAhead - NPF, kfirst - kAhead), KF1 = K1 - kAhead - NPF;
   int it1 = (KF0 - base + NPF - 1) / NPF;
   int it2 = (KF1 - base) / NPF;
   it1 = min(max(it1, 0), NIT);
@@ -1053,6 +1115,9 @@ __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
   const int dir = b2 / B, b = b2 - dir * B;
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
+#if defined(FTR_TRACE) && FTR_TRACE == 2
+  if (threadIdx.x == 0) { const u64 t = trace_now(); atomicMin(&g_trace[0], t); if (b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[2] = t; }
+#endif
   const Bound bd = load_boundary(boundary, b, S, T);
   const int T1 = MOD ? T : T + 1;
   const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
@@ -1105,9 +1170,13 @@ __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
   // that reaches it) are different buffers: no workgroup reads what another one writes
   if (dir == 0) bidir_flow_body<MOD, true>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, check, ctrl, b, w, Tg, S, T, cut.D - cut.jm);
   else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, nullptr, ctrl, b, w, Tg, S, T, cut.jm);
+#if defined(FTR_TRACE) && FTR_TRACE == 2
+  __builtin_amdgcn_s_waitcnt(kVmcnt0);
+  if (lane == 0) { const u64 t = trace_now(); atomicMax(&g_trace[1], t); if (wid == 0 && b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[3] = t; }
+#endif
 }
 
-inline size_t bidir_lds_bytes() { return (size_t)8 * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }   // forward: 8 tiles + ring; flow: 6 tiles + 2 rings
+inline size_t bidir_lds_bytes() { return (size_t)kFwdTiles * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }   // forward: 10 tiles + ring; flow: 9 tiles + ring
 
 // The workgroup dispatcher fills a CU up to its resource limits before it moves on: with 26 KB of LDS per workgroup
 // it co-locates workgroups on a few CUs of each XCD while others idle, and the co-located compute waves (one chain
@@ -1302,6 +1371,22 @@ int selftest(hipStream_t st, int* result_dev) {
   }
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, in, out, result_dev);
   return check_launch("selftest");
+}
+
+// diagnostic (-DFTR_TRACE builds): reads the timeline (n <= kTraceN words) and re-arms it (min slot = ~0, the rest 0)
+int debug_trace(unsigned long long* out, int n) {
+  static unsigned long long init[kTraceN];
+  if (n < 0 || n > kTraceN) { set_error("debug_trace: n out of range"); return FTR_ERR_INVALID_ARG; }
+  if (hipDeviceSynchronize() != hipSuccess ||
+      (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n) != hipSuccess)) {
+    (void)hipGetLastError(); set_error("debug_trace: copy failed"); return FTR_ERR_LAUNCH;
+  }
+  for (int i = 0; i < kTraceN; ++i) init[i] = 0;
+  init[0] = ~0ull;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace), init, sizeof(init)) != hipSuccess) {
+    (void)hipGetLastError(); set_error("debug_trace: reset failed"); return FTR_ERR_LAUNCH;
+  }
+  return FTR_OK;
 }
 
 // diagnostic (make STAMPS=1): see FTR_SYNC above

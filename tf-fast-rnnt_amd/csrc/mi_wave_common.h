@@ -26,6 +26,19 @@ static __device__ unsigned long long g_stamps[16];  // read back by debug_stamps
 #define FTR_STAMP(var) do { } while (0)
 #endif
 
+// Diagnostic build only (-DFTR_TRACE=1 forward / =2 flow): a timeline in s_memrealtime ticks (100 MHz):
+// g_trace[0] = earliest workgroup start, [1] = latest workgroup end (all workgroups, atomics), [2] / [3] = start / end of
+// the traced workgroup (utterance 0, direction FTR_TRACE_DIR, band FTR_STAMP_BAND), [4] = slots recorded,
+// [16 + k] = time at which the traced workgroup's compute wave left the barrier of slot k.  Reset + read: ftr_debug_trace().
+constexpr int kTraceN = 1024;
+static __device__ unsigned long long g_trace[kTraceN];
+#ifdef FTR_TRACE
+#ifndef FTR_TRACE_DIR
+#define FTR_TRACE_DIR 0
+#endif
+__device__ __forceinline__ unsigned long long trace_now() { return __builtin_amdgcn_s_memrealtime(); }
+#endif
+
 __device__ __forceinline__ float dpp_wave_shr1(float old_for_lane0, float src) {
   // lane l (l >= 1) receives src of lane l-1; lane 0 keeps `old_for_lane0` (bound_ctrl = 0).
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old_for_lane0),

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "ftr_simple_logprobs_bwd_lm_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _c_fp, _i, _i, _i, _c_st]),
     "ftr_selftest": (_i, [ctypes.c_void_p, _c_st]),
     "ftr_debug_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
+    "ftr_debug_trace": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 FTR_MI_WS_CLEAN = 1   # include/ftr.h
