@@ -85,6 +85,10 @@ __host__ __device__ inline int granules_per_band(int T, int modified) {
   const int nchunks = (T + 1 + (modified ? 0 : 63) + CH - 1) / CH;
   return CH * (nchunks + 1);
 }
+// floats in front of the first ratio lattice: the flow kernel's unguarded 16-byte loads may start up to 66 elements before
+// a lattice row (skewed quads of edge chunks; masked after the load) -- for the first row of the first utterance that is
+// in front of the lattice, and has to stay inside the workspace
+constexpr size_t kLatPad = 128;
 __host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
   size_t L = (size_t)B * (S + 1) * (T + 1);
   return (L + 3) & ~(size_t)3;
@@ -155,10 +159,10 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
   constexpr int NPF = FTR_NPF_FWD;
-  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK: the compute wave reads it from the ring during
-  // slot kc + 1 (into registers) and uses it in slot kc + 2 for its chunk kc + 2, which needs the upper chunk kc + 2 + 4
-  // (regular: lane 0's neighbour is 63 steps ahead, plus one carried element) / kc + 2 (modified)
-  constexpr int LOOK = MOD ? 2 : 6;
+  // at slot kc the COMM wave imports the upper band's chunk kc + LOOK: the compute wave reads it from the ring at the
+  // start of slot kc + 1 for its chunk kc + 1, which needs the upper chunk kc + 1 + 4 (regular: lane 0's neighbour is
+  // 63 steps ahead, plus one carried element) / kc + 1 (modified)
+  constexpr int LOOK = MOD ? 1 : 5;
   constexpr int PRE = NPF + kAhead;  // IO pipeline warm-up slots in front of chunk 0
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
@@ -205,7 +209,9 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     // between) one slot ahead, while the previous chunk is computed, so that the dependent chain below never waits for
     // the LDS (measured: with the reads issued one quad ahead, behind that quad's tile writes in the in-order LDS queue,
     // every quad paid a full LDS round trip -- 1529 of the slot's 1729 cycles were this wave, profiles/r02_b_stamps_stage1.log).
-    struct Ops { f4 X[NQ], Y[NQ], E[NQ]; };
+    // (The band above's values -- four broadcast reads -- are read at the start of the slot that uses them: one slot
+    // less of hand-off lag per band than reading them a slot ahead with the tiles.)
+    struct Ops { f4 X[NQ], Y[NQ]; };
     auto fetch = [&](int k, Ops& o) {
       const f4* cX = FTR_TX(k);
       const f4* cY = FTR_TY(k);
@@ -213,15 +219,17 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       for (int q = 0; q < NQ; ++q) {
         o.X[q] = cX[q * PLANE + lane];
         o.Y[q] = cY[q * PLANE + lane];
-        o.E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
       }
     };
     auto compute_chunk = [&](int k, const Ops& o) {
       f4* cD = FTR_TD(k);
       f4* cP = FTR_TP(k);
+      f4 E[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const f4 X4 = o.X[q], Y4 = o.Y[q], E4 = o.E[q];
+        const f4 X4 = o.X[q], Y4 = o.Y[q], E4 = E[q];
         f4 XE;
         XE[0] = __builtin_fmaf(lane0, ecarry, X4[0]); XE[1] = __builtin_fmaf(lane0, E4[0], X4[1]);
         XE[2] = __builtin_fmaf(lane0, E4[1], X4[2]);  XE[3] = __builtin_fmaf(lane0, E4[2], X4[3]);
@@ -248,16 +256,12 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     // slot kc: fetch chunk kc + 1 (parked during slot kc - 1), compute chunk kc from the registers fetched during
     // slot kc - 1.  Two register sets, the loop is unrolled by two so that they swap roles without copies.
     Ops oa, ob;
-    float ecarry0 = kNeg;
     auto slot = [&](int kc, const Ops& cur, Ops& nxt) {
-      if (kc + 1 >= 0 && kc + 1 < klast) {
-        fetch(kc + 1, nxt);
+      if (kc + 1 >= 0 && kc + 1 < klast) fetch(kc + 1, nxt);
+      if (kc >= 0 && kc < klast) {
         // the element in front of chunk 0's first ring value: the band above's step 63 (regular; imported with its
         // chunk 3 by now), nothing (modified: the ring still holds its initial -inf there)
-        if (kc + 1 == 0) ecarry0 = in_ring[RINGN - 1];
-      }
-      if (kc >= 0 && kc < klast) {
-        if (kc == 0) ecarry = ecarry0;
+        if (kc == 0) ecarry = in_ring[RINGN - 1];
 #ifndef FTR_EXP_NOCOMPUTE
         compute_chunk(kc, cur);
 #endif
@@ -287,24 +291,8 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
-      if (kc - 1 >= 0 && kc - 1 < klast) {
-        const float* tp = reinterpret_cast<const float*>(FTR_TP(kc - 1));
-#ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
-        if (has_down && lane < CH && !(w == 0 && !REVM)) {
-#else
-        if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk kc-1 -> granules of the band below
-#endif
-          const int m = kc - 1;
-          const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
-          const u64 g = ((u64)(unsigned)(m + 1) << 32) | (u64)__float_as_uint(v);
-          __hip_atomic_store(gran_out + CH * m + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (kc - 1 == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
-          pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
-      }
       const int m = kc + LOOK;
-      u64 g_next = 0;
-      if (has_up && !dead && m + 1 >= 0 && m + 1 < klast_up) g_next = comm_peek(gran_in, m + 1, lane);
+      // import first: it waits for the peek issued one slot ago only, never for this slot's publishing stores
 #ifdef FTR_EXP_NOPOLL
       if (false) {
 #else
@@ -315,7 +303,24 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           in_ring[lane] = __builtin_nanf("");
         }
       }
-      g_cur = g_next;
+      // the next chunk's granules are requested now and looked at one whole slot later
+      g_cur = 0;
+      if (has_up && !dead && m + 1 >= 0 && m + 1 < klast_up) g_cur = comm_peek(gran_in, m + 1, lane);
+      if (kc - 1 >= 0 && kc - 1 < klast) {
+        const float* tp = reinterpret_cast<const float*>(FTR_TP(kc - 1));
+#ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
+        if (has_down && lane < CH && !(w == 0 && !REVM)) {
+#else
+        if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk kc-1 -> granules of the band below
+#endif
+          const int mm = kc - 1;
+          const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
+          const u64 g = ((u64)(unsigned)(mm + 1) << 32) | (u64)__float_as_uint(v);
+          __hip_atomic_store(gran_out + CH * mm + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (kc - 1 == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
+          pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
+      }
       FTR_SYNC();
     }
     FTR_SYNC_REPORT(2);
@@ -345,7 +350,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
             const ptrdiff_t o = (ptrdiff_t)(bd.sb + r - 1) * T1 + bd.tb + cx;
             if (cx >= 0 && c0 + 3 < Tn) {
               vx = *reinterpret_cast<const f4u*>(px + o);
-            } else {
+            } else if (cx + 3 >= 0 && c0 < Tn) {   // a quad that straddles the edge: rare, skipped when no lane has one
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (cx + e >= 0 && c0 + e < Tn) vx[e] = px[o + e];
@@ -355,7 +360,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
             const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * T + bd.tb + c0 - 1;
             if (c0 >= 1 && c0 + 3 < Tn) {
               vy = *reinterpret_cast<const f4u*>(py + o);
-            } else {
+            } else if (c0 + 3 >= 1 && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (c0 + e >= 1 && c0 + e < Tn) vy[e] = py[o + e];
@@ -369,7 +374,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
             const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * T1 + bd.te - c0 - 3;
             if (c0 >= NOFF && c0 + 3 < Tn) {
               vx = *reinterpret_cast<const f4u*>(px + lo);      // memory order; park() reverses
-            } else {
+            } else if (c0 + 3 >= NOFF && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (c0 + e >= NOFF && c0 + e < Tn) vx[3 - e] = px[lo + 3 - e];
@@ -379,7 +384,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
             const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * T + bd.te - c0 - 3;
             if (c0 >= 1 && c0 + 3 < Tn) {
               vy = *reinterpret_cast<const f4u*>(py + lo);
-            } else {
+            } else if (c0 + 3 >= 1 && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (c0 + e >= 1 && c0 + e < Tn) vy[3 - e] = py[lo + 3 - e];
@@ -393,18 +398,48 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   };
   // kk = chunk being parked.  The origin cell (chunk 0, tile row 0, quad 0, element 0 of band 0) gets Y := 0 so that
   // p = logadd(-inf, pcur(0) + 0) = 0 falls out of the recursion.
-  bool nan_seen = false;   // a NaN among the px / py values this lane staged (reported through uflags: ans = NaN)
-  auto park = [&](int kk, const f4 (&x)[4], const f4 (&y)[4]) {
+  // NaN detection among the px / py values this lane stages (reported through uflags: ans = NaN): the running maximum of
+  // the magnitudes' bit patterns exceeds that of infinity iff a NaN went by (two VALU instructions per value, no branches)
+  unsigned nan_acc = 0;
+  // v'[j] = v[j + d] (memory order): realigns a quad whose load address was clamped into the utterance's slab; the
+  // elements that fall off are outside the slab, hence outside the boundary rectangle, and are masked by the caller
+  auto shift4 = [](const f4 v, int d) {
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = j + d;
+      o[j] = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
+    }
+    return o;
+  };
+  const int xmaxo = S * T1 - 4, ymaxo = (S + 1) * T - 4;    // last element offset a 16-byte load may start at
+  auto park = [&](int kk, const f4 (&xin)[4], const f4 (&yin)[4], auto edge_tag, int (&offXr)[4], int (&offYr)[4]) {
+    constexpr bool edge = decltype(edge_tag)::value;   // compile time: the interior variant carries none of the masking
     f4* dX = FTR_TX(kk);
     f4* dY = FTR_TY(kk);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = 16 * m + frow;
+      f4 xm = xin[m], ym = yin[m];
+      const int c0 = CH * kk + 4 * fq - SKEW * row;   // walk column of the quad's first step
+      if (edge) {   // the chunk has quads outside [1, Tn)
+        const int dk = REVM ? -CH * kk : CH * kk;
+        const int wx = offXr[m] + dk, wy = offYr[m] + dk;
+        const int dx = wx - min(max(wx, 0), xmaxo), dy = wy - min(max(wy, 0), ymaxo);
+        if (dx != 0) xm = shift4(xm, dx);
+        if (dy != 0) ym = shift4(ym, dy);
+      }
       f4 xs, ys;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float vx = x[m][REVM ? 3 - e : e] * kLog2e, vy = y[m][REVM ? 3 - e : e] * kLog2e;   // log2 domain; REV: swap
-        nan_seen = nan_seen || (vx != vx) || (vy != vy);
+        float rx_ = xm[REVM ? 3 - e : e], ry_ = ym[REVM ? 3 - e : e];   // REV: registers are in memory order
+        if (edge) {   // columns outside the rectangle: "impossible transition" (what is there is padding, not data)
+          const int c = c0 + e;
+          rx_ = (c >= NOFF && c < Tn) ? rx_ : -INFINITY;
+          ry_ = (c >= 1 && c < Tn) ? ry_ : -INFINITY;
+        }
+        const float vx = rx_ * kLog2e, vy = ry_ * kLog2e;   // log2 domain
+        nan_acc = max(nan_acc, max(__float_as_uint(vx) & 0x7fffffffu, __float_as_uint(vy) & 0x7fffffffu));
         xs[e] = fmaxf(vx, kNeg);  // -inf -> kNeg (a NaN too: the chain stays finite, the utterance is flagged instead)
         ys[e] = fmaxf(vy, kNeg);
       }
@@ -438,7 +473,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
           if (c0 >= 0 && c0 + 3 < Tn) {
             *reinterpret_cast<f4u*>(wsb + o) = g;
-          } else {
+          } else if (c0 + 3 >= 0 && c0 < Tn) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (c0 + e >= 0 && c0 + e < Tn) wsb[o + e] = g[e];
@@ -447,7 +482,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
           if (c0 >= 0 && c0 + 3 < Tn) {
             *reinterpret_cast<f4u*>(wsb + lo) = rev4(g);
-          } else {
+          } else if (c0 + 3 >= 0 && c0 < Tn) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (c0 + e >= 0 && c0 + e < Tn) wsb[lo + 3 - e] = g[e];
@@ -483,23 +518,18 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     }
     rvalid[m] = r < Sn;
   }
+  // The same eight 16-byte loads for EVERY chunk, edge chunks included: the start of each load is clamped into the
+  // utterance's own slab of px / py (a quad may hang over the valid columns by up to 3 elements, which is inside the
+  // slab except at its two ends); park() realigns the clamped quads and masks the columns outside the rectangle.  A
+  // fixed instruction sequence keeps the waits of the prefetch pipeline counted (s_waitcnt vmcnt(n > 0)) in every
+  // slot: with per-element guarded loads in the edge chunks each of those slots waited for vmcnt(0), a full memory
+  // round trip, and the bands below inherited the stall (profiles/r02_c_kernel_timelines_stage2.log).
   auto load_fast = [&](int k, f4 (&x)[4], f4 (&y)[4]) {
-    if (!REVM) {
-      const float* px_k = px + CH * k;   // wave-uniform part of the address
-      const float* py_k = py + CH * k;
+    const int dk = REVM ? -CH * k : CH * k;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        x[m] = *reinterpret_cast<const f4u*>(px_k + offX[m]);
-        y[m] = *reinterpret_cast<const f4u*>(py_k + offY[m]);
-      }
-    } else {
-      const float* px_k = px - CH * k;
-      const float* py_k = py - CH * k;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        x[m] = *reinterpret_cast<const f4u*>(px_k + offX[m]);   // memory order, see load_general
-        y[m] = *reinterpret_cast<const f4u*>(py_k + offY[m]);
-      }
+    for (int m = 0; m < 4; ++m) {
+      x[m] = *reinterpret_cast<const f4u*>(px + min(max(offX[m] + dk, 0), xmaxo));   // REV: memory order, see load_general
+      y[m] = *reinterpret_cast<const f4u*>(py + min(max(offY[m] + dk, 0), ymaxo));
     }
   };
   auto drain_fast = [&](int k) {
@@ -540,41 +570,67 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   }
 
   // --------------------------------------------------------------------------- IO-in
+  // degenerate slabs (fewer than 4 elements of px or py per utterance, or no px at all): guarded element loads
+  const bool tiny = xmaxo < 0 || ymaxo < 0;
   auto slot_general = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    if (kc + kAhead >= 0 && kc + kAhead < klast) park(kc + kAhead, x, y);
+    if (kc + kAhead >= 0 && kc + kAhead < klast) park(kc + kAhead, x, y, std::false_type{}, offX, offY);
     if (kc + kAhead + NPF >= 0 && kc + kAhead + NPF < klast) load_general(kc + kAhead + NPF, x, y);
     FTR_SYNC();
   };
-  auto slot_fast = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    park(kc + kAhead, x, y);         // loads of chunk kc+kAhead were issued NPF slots ago
-    load_fast(kc + kAhead + NPF, x, y);
+  // an edge chunk has quads outside [1, Tn); readfirstlane: the compiler must see the flag as wave-uniform, or it runs
+  // the masking code under an exec mask in every slot (seen: the slot of this wave doubled)
+  auto is_edge = [&](int k) { return __builtin_amdgcn_readfirstlane((int)!(k >= K0 && k < K1)) != 0; };
+  // pipeline fill and drain: the chunk to park / to load may not exist
+  auto slot_cond = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
+    const int kp = kc + kAhead, kl = kc + kAhead + NPF;
+    if (kp >= 0 && kp < klast) {
+      if (is_edge(kp)) park(kp, x, y, std::true_type{}, offX, offY);
+      else park(kp, x, y, std::false_type{}, offX, offY);
+    }
+    if (kl >= 0 && kl < klast) load_fast(kl, x, y);
+    FTR_SYNC();
+  };
+  auto slot_steady = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
+    const int kp = kc + kAhead;
+    // loads of chunk kp were issued NPF slots ago; VALU / LDS work only inside the (wave-uniform) branch
+    if (is_edge(kp)) park(kp, x, y, std::true_type{}, offX, offY);
+    else park(kp, x, y, std::false_type{}, offX, offY);
+    load_fast(kp + NPF, x, y);
     FTR_SYNC();
   };
 
-  // Fast slot kc: the loaded chunk kc+kAhead+NPF is interior and inside [0, klast), the parked chunk kc+kAhead exists.
-  const int KF0 = max(K0 - kAhead - NPF, -kAhead), KF1 = (Sn >= 2) ? K1 - kAhead - NPF : 0;      // fast slots: KF0 <= kc < KF1
+  // steady slot kc: the parked chunk kc+kAhead and the loaded chunk kc+kAhead+NPF both exist
+  const int KF0 = -kAhead, KF1 = tiny ? KF0 : klast - kAhead - NPF;      // steady slots: KF0 <= kc < KF1
   int it1 = (KF0 - base + NPF - 1) / NPF;                // first iteration whose first slot has kc >= KF0
   int it2 = (KF1 - base) / NPF;                          // first iteration whose last slot has kc >= KF1
   it1 = min(max(it1, 0), NIT);
   it2 = min(max(it2, it1), NIT);
 
   int it = 0;
+  if (tiny) {
+    for (; it < NIT; ++it) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+    }
+  }
   for (; it < it1; ++it) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+    for (int u = 0; u < NPF; ++u) slot_cond(base + NPF * it + u, rx[u], ry[u]);
   }
   if (it < it2) {
-    __builtin_amdgcn_s_waitcnt(kVmcnt0);  // nothing pending when the steady-state loop is entered
+    // nothing pending when the steady-state loop is entered: with a known state at both loop entries the compiler
+    // keeps the waits inside the loop counted (vmcnt(n > 0)) instead of falling back to vmcnt(0) in every slot
+    __builtin_amdgcn_s_waitcnt(kVmcnt0);
     for (; it < it2; ++it) {
 #pragma unroll
-      for (int u = 0; u < NPF; ++u) slot_fast(base + NPF * it + u, rx[u], ry[u]);
+      for (int u = 0; u < NPF; ++u) slot_steady(base + NPF * it + u, rx[u], ry[u]);
     }
   }
   for (; it < NIT; ++it) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+    for (int u = 0; u < NPF; ++u) slot_cond(base + NPF * it + u, rx[u], ry[u]);
   }
-  if (__any(nan_seen) && lane == 0) __hip_atomic_fetch_or(uflag_b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__any(nan_acc > 0x7f800000u) && lane == 0) __hip_atomic_fetch_or(uflag_b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   FTR_SYNC_REPORT(1);
 }
 
@@ -591,10 +647,18 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 __device__ __forceinline__ float pmid_load(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void cut_reduce(float* red, const float* __restrict__ pa, const float* __restrict__ pb,
-                                           float* __restrict__ ob, float* __restrict__ ans_b, int Sn, bool poisoned) {
+__device__ __forceinline__ void cut_reduce(float* red, float* cache, int cache_n, const float* __restrict__ pa,
+                                           const float* __restrict__ pb, float* __restrict__ ob,
+                                           float* __restrict__ ans_b, int Sn, bool poisoned) {
+  // one pass over the (remote) cut values: p + q goes to an LDS cache while the maximum is formed; the sum and the
+  // occupancies come from the cache (rows beyond the cache, Sn > cache_n, are re-read)
+  auto val = [&](int r) { return r < cache_n ? cache[r] : pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r); };
   float m = -INFINITY;
-  for (int r = threadIdx.x; r < Sn; r += 256) m = fmaxf(m, pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r));
+  for (int r = threadIdx.x; r < Sn; r += 256) {
+    const float v = pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r);
+    if (r < cache_n) cache[r] = v;
+    m = fmaxf(m, v);
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -602,7 +666,7 @@ __device__ __forceinline__ void cut_reduce(float* red, const float* __restrict__
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float sum = 0.0f;
-  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f(pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r) - m);
+  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f(val(r) - m);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
@@ -616,7 +680,7 @@ __device__ __forceinline__ void cut_reduce(float* red, const float* __restrict__
   // rounding, whatever the magnitude of p + q (thousands on long utterances)
   const float inv = 1.0f / sum;
   for (int r = threadIdx.x; r < Sn; r += 256)
-    ob[r] = (dead || poisoned) ? 0.0f : exp2f(pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r) - m) * inv;
+    ob[r] = (dead || poisoned) ? 0.0f : exp2f(val(r) - m) * inv;
 }
 
 struct Ctrl {           // int offsets into the ctrl block of the workspace
@@ -654,7 +718,7 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   const int T1 = MOD ? T : T + 1;
   const float* pxb = px + (size_t)b * S * T1;
   const float* pyb = py + (size_t)b * (S + 1) * T;
-  float* wsb = ws + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
+  float* wsb = ws + kLatPad + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
   u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
   float* pmid_b = pmid + ((size_t)dir * B + b) * (S + 1);
   const Ctrl c = ctrl_of(ctrl, B);
@@ -681,8 +745,8 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
     __hip_atomic_store(c.done + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(c.uflags + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  cut_reduce(reinterpret_cast<float*>(smem) + 4, pmid + (size_t)b * (S + 1), pmid + ((size_t)B + b) * (S + 1),
-             occ + (size_t)b * (S + 1), ans + b, Sn, (uf | stt) != 0);
+  cut_reduce(reinterpret_cast<float*>(smem) + 4, reinterpret_cast<float*>(smem) + 8, 8192, pmid + (size_t)b * (S + 1),
+             pmid + ((size_t)B + b) * (S + 1), occ + (size_t)b * (S + 1), ans + b, Sn, (uf | stt) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------- flow
@@ -705,7 +769,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
   constexpr int NPF = FTR_NPF_FLOW;
-  constexpr int LOOK = MOD ? 2 : 6;      // see the forward body
+  constexpr int LOOK = MOD ? 1 : 5;      // see the forward body
   constexpr int PRE = NPF + kAhead;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
@@ -753,24 +817,24 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     float yprev = 0.0f, xprev = 0.0f, ecarry = 0.0f;
 
     // operands of a whole chunk in registers, fetched one slot ahead (see the forward body)
-    struct Ops { f4 G[NQ], E[NQ]; };
+    struct Ops { f4 G[NQ]; };
     auto fetch = [&](int k, Ops& o) {
       const f4* cG = FTR_TG(k);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        o.G[q] = cG[q * PLANE + lane];
-        o.E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];
-      }
+      for (int q = 0; q < NQ; ++q) o.G[q] = cG[q * PLANE + lane];
     };
     auto compute_chunk = [&](int k, const Ops& o, auto inject_tag) {
       constexpr bool INJ = decltype(inject_tag)::value;
       f4* cPX = FTR_TPX(k);
       f4* cPY = FTR_TPY(k);
       f4* cXO = FTR_TXO(k);
+      f4 E[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int j0 = CH * k + 4 * q;
-        const f4 G4 = o.G[q], E4 = o.E[q];
+        const f4 G4 = o.G[q], E4 = E[q];
         f4 XO4, PX4, PY4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -795,16 +859,12 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     };
 
     Ops oa, ob;
-    float ecarry0 = 0.0f;
     auto slot = [&](int kc, const Ops& cur, Ops& nxt) {
-      if (kc + 1 >= kfirst && kc + 1 < nchunks) {
-        fetch(kc + 1, nxt);
-        if (kc + 1 == kfirst) ecarry0 = in_ring[(CH * kfirst - 1) & (RINGN - 1)];   // the element in front of the first chunk
-      }
+      if (kc + 1 >= kfirst && kc + 1 < nchunks) fetch(kc + 1, nxt);
 #ifndef FTR_EXP_FLOW_NOCOMPUTE
       if (kc >= kfirst && kc < nchunks) {
         if (kc == kfirst) {
-          ecarry = ecarry0;
+          ecarry = in_ring[(CH * kfirst - 1) & (RINGN - 1)];   // the element in front of the first chunk
           compute_chunk(kc, cur, std::true_type{});
         } else {
           compute_chunk(kc, cur, std::false_type{});
@@ -843,7 +903,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
           if (c0 >= 0 && c0 + 3 < Tn) {
             v = *reinterpret_cast<const f4u*>(wsb + lo);          // memory order; park() reverses
-          } else {
+          } else if (c0 + 3 >= 0 && c0 < Tn) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (c0 + e >= 0 && c0 + e < Tn) v[3 - e] = wsb[lo + 3 - e];
@@ -852,7 +912,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
           if (c0 >= 0 && c0 + 3 < Tn) {
             v = *reinterpret_cast<const f4u*>(wsb + o);
-          } else {
+          } else if (c0 + 3 >= 0 && c0 < Tn) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (c0 + e >= 0 && c0 + e < Tn) v[e] = wsb[o + e];
@@ -862,10 +922,19 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       gq[m] = v;
     }
   };
-  auto park = [&](int kk, const f4 (&gq)[4]) {
+  auto park = [&](int kk, const f4 (&gq)[4], auto edge_tag) {
+    constexpr bool edge = decltype(edge_tag)::value;
     f4* dG = FTR_TG(kk);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) dG[fq * PLANE + 16 * m + frow] = REVM ? rev4(gq[m]) : gq[m];   // REV loads stay in memory order until here
+    for (int m = 0; m < 4; ++m) {
+      f4 g = REVM ? rev4(gq[m]) : gq[m];   // REV loads stay in memory order until here
+      if (edge) {   // wave-uniform: columns outside [0, Tn) hold no ratio (whatever was loaded there): no flow
+        const int c0 = CH * kk + 4 * fq - SKEW * (16 * m + frow);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (c0 + e >= 0 && c0 + e < Tn) ? g[e] : 0.0f;
+      }
+      dG[fq * PLANE + 16 * m + frow] = g;
+    }
   };
   // Steps up to and including the cut (local walk step <= jli) belong to the other half and are never written.
   auto drain_general = [&](int k, auto xtag, auto ytag) {
@@ -889,7 +958,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
             const ptrdiff_t lo = (ptrdiff_t)s * T1 + bd.te - c0 - 3;
             if (whole && c0 >= NOFF && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pxg + lo) = rev4(gx);
-            } else {
+            } else if (jq + 3 > jli && c0 + 3 >= NOFF && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (jq + e > jli && c0 + e >= NOFF && c0 + e < Tn) pxg[lo + 3 - e] = gx[e];
@@ -899,7 +968,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
             const ptrdiff_t lo = (ptrdiff_t)s * T + bd.te - c0 - 3;
             if (whole && c0 >= 1 && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pyg + lo) = rev4(gy);
-            } else {
+            } else if (jq + 3 > jli && c0 + 3 >= 1 && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (jq + e > jli && c0 + e >= 1 && c0 + e < Tn) pyg[lo + 3 - e] = gy[e];
@@ -911,7 +980,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
             const ptrdiff_t o = (ptrdiff_t)(bd.sb + r - 1) * T1 + bd.tb + cx;
             if (whole && cx >= 0 && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pxg + o) = gx;
-            } else {
+            } else if (jq + 3 > jli && cx + 3 >= 0 && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (jq + e > jli && cx + e >= 0 && c0 + e < Tn) pxg[o + e] = gx[e];
@@ -921,7 +990,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
             const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * T + bd.tb + c0 - 1;
             if (whole && c0 >= 1 && c0 + 3 < Tn) {
               *reinterpret_cast<f4u*>(pyg + o) = gy;
-            } else {
+            } else if (jq + 3 > jli && c0 + 3 >= 1 && c0 < Tn) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 if (jq + e > jli && c0 + e >= 1 && c0 + e < Tn) pyg[o + e] = gy[e];
@@ -998,9 +1067,10 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 
   if (wid == 2) {
     // ======================================================================= COMM wave
-    // hand-off to the band below (lane 63's xout of every step, read from the XO tile), the ans_grad self check,
-    // this band's py_grad stores (the IO-out wave keeps the px_grad stores: two balanced store streams), and the
-    // import of the band above's flow.  The stores are issued before the poll, so a late producer cannot delay them.
+    // the import of the band above's flow (first: it only waits for the peek issued one slot ago and for stores that are
+    // a slot old), the request for the next chunk's granules, the hand-off to the band below (lane 63's xout of every
+    // step, read from the XO tile), the ans_grad self check and this band's py_grad stores (the IO-out wave keeps the
+    // px_grad stores: two balanced store streams).
     u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
     u64* gran_in = gran_b + (size_t)w * Tg;
     const bool has_up = w > 0, has_down = w + 1 < NWact;
@@ -1012,6 +1082,16 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int k = kc - 1;
+      const int m = kc + LOOK;
+      if (has_up && !dead && m >= kfirst_up && m < nchunks) {
+        if (!comm_import(in_ring, gran_in, m, lane, g_cur, status)) {
+          dead = true;
+          in_ring[lane] = __builtin_nanf("");
+        }
+      }
+      // the next chunk's granules are requested now and looked at one whole slot later
+      g_cur = 0;
+      if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_cur = comm_peek(gran_in, m + 1, lane);
       if (k >= kfirst && k < nchunks) {
         if (has_down && k >= kpub && lane < CH) {
           const float* txo = reinterpret_cast<const float*>(FTR_TXO(k));
@@ -1028,16 +1108,6 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
         if (k >= K0d && k < K1) drain_fast(k, std::false_type{}, std::true_type{});   // wave-uniform
         else drain_general(k, std::false_type{}, std::true_type{});
       }
-      const int m = kc + LOOK;
-      u64 g_next = 0;
-      if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_next = comm_peek(gran_in, m + 1, lane);
-      if (has_up && !dead && m >= kfirst_up && m < nchunks) {
-        if (!comm_import(in_ring, gran_in, m, lane, g_cur, status)) {
-          dead = true;
-          in_ring[lane] = __builtin_nanf("");
-        }
-      }
-      g_cur = g_next;
       FTR_FSYNC();
     }
     FTR_FREPORT(2);
@@ -1059,19 +1129,29 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   }
 
   // --------------------------------------------------------------------------- IO-in
-  auto slot_general = [&](int kc, f4 (&gq)[4]) {
-    if (kc + kAhead >= kfirst && kc + kAhead < nchunks) park(kc + kAhead, gq);
-    if (kc + kAhead + NPF >= kfirst && kc + kAhead + NPF < nchunks) load_general(kc + kAhead + NPF, gq);
+  // The same four unguarded 16-byte loads for every chunk (the lattices have kLatPad floats in front and the cut vectors
+  // behind them, so a quad hanging over a row's valid columns stays inside the workspace); park() masks the columns
+  // outside [0, Tn).  A fixed instruction sequence keeps the prefetch pipeline's waits counted in every slot.
+  auto is_edge = [&](int k) { return __builtin_amdgcn_readfirstlane((int)!(k >= K0 && k < K1)) != 0; };   // wave-uniform for the compiler too
+  auto slot_cond = [&](int kc, f4 (&gq)[4]) {     // pipeline fill and drain: the chunk to park / to load may not exist
+    const int kp = kc + kAhead, kl = kc + kAhead + NPF;
+    if (kp >= kfirst && kp < nchunks) {
+      if (is_edge(kp)) park(kp, gq, std::true_type{});
+      else park(kp, gq, std::false_type{});
+    }
+    if (kl >= kfirst && kl < nchunks) load_fast(kl, gq);
     FTR_FSYNC();
   };
-  auto slot_fast = [&](int kc, f4 (&gq)[4]) {
-    park(kc + kAhead, gq);
-    load_fast(kc + kAhead + NPF, gq);
+  auto slot_steady = [&](int kc, f4 (&gq)[4]) {
+    const int kp = kc + kAhead;
+    if (is_edge(kp)) park(kp, gq, std::true_type{});
+    else park(kp, gq, std::false_type{});
+    load_fast(kp + NPF, gq);
     FTR_FSYNC();
   };
 
-  // fast slot kc: loaded chunk kc+kAhead+NPF interior (and not before the cut's chunk), parked chunk kc+kAhead exists
-  const int KF0 = max(K0 - kAhead - NPF, kfirst - kAhead), KF1 = K1 - kAhead - NPF;
+  // steady slot kc: the parked chunk kc+kAhead and the loaded chunk kc+kAhead+NPF both exist
+  const int KF0 = kfirst - kAhead, KF1 = nchunks - kAhead - NPF;
   int it1 = (KF0 - base + NPF - 1) / NPF;
   int it2 = (KF1 - base) / NPF;
   it1 = min(max(it1, 0), NIT);
@@ -1080,18 +1160,18 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   int it = 0;
   for (; it < it1; ++it) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
+    for (int u = 0; u < NPF; ++u) slot_cond(base + NPF * it + u, rg[u]);
   }
   if (it < it2) {
-    __builtin_amdgcn_s_waitcnt(kVmcnt0);
+    __builtin_amdgcn_s_waitcnt(kVmcnt0);   // known state at the loop entry: the waits inside stay counted (see the forward body)
     for (; it < it2; ++it) {
 #pragma unroll
-      for (int u = 0; u < NPF; ++u) slot_fast(base + NPF * it + u, rg[u]);
+      for (int u = 0; u < NPF; ++u) slot_steady(base + NPF * it + u, rg[u]);
     }
   }
   for (; it < NIT; ++it) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rg[u]);
+    for (int u = 0; u < NPF; ++u) slot_cond(base + NPF * it + u, rg[u]);
   }
   FTR_FREPORT(1);
 }
@@ -1161,7 +1241,7 @@ __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
   }
   if (w >= ((Sn + 63) >> 6)) return;
   const Cut cut = make_cut<MOD>(Sn, Tn);
-  const float* wsb = ws + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
+  const float* wsb = ws + kLatPad + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
   u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
   const float* occ_b = occ + (size_t)b * (S + 1);
   // dir 0 holds the alpha ratios: its flow runs in REV addressing from the cut (walk step D - jm) to the origin;
@@ -1211,7 +1291,7 @@ struct BidirLayout {
 inline BidirLayout bidir_layout(int B, int S, int T) {
   BidirLayout l;
   l.lat = lattice_floats(B, S, T);
-  l.pmid_off = 2 * l.lat;
+  l.pmid_off = kLatPad + 2 * l.lat;
   l.occ_off = l.pmid_off + 2 * (size_t)B * (S + 1);
   l.seed_off = l.occ_off + (size_t)B * (S + 1);
   l.ctrl_off = (l.seed_off + (size_t)B + 3) & ~(size_t)3;
