@@ -104,38 +104,128 @@ __global__ void prune_argmax_kernel(const float* __restrict__ px_grad, const flo
   s_begin[(size_t)b * T + t] = (t < te - 1) ? best : pad;                // :741-748
 }
 
-// one wave per utterance: two right-to-left min-scans over T with a register carry.
-__global__ void prune_adjust_kernel(int32_t* __restrict__ s_begin, int32_t* __restrict__ ranges, int B,
+// The same with the window length as a template parameter (1 <= R <= 16): every py_grad value is LOADED ONCE.  The lag
+// cumsum consumes, R rows later, what the lead cumsum loaded (carried in registers across chunks), in the same order
+// and with the same additions, so the sums -- and the ranges -- are bit-identical to the kernel above.
+template <int R>
+__global__ void prune_argmax_once_kernel(const float* __restrict__ px_grad, const float* __restrict__ py_grad,
+                                         const int32_t* __restrict__ boundary, int32_t* __restrict__ s_begin,
+                                         int B, int S, int T, int T1) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const int S1 = S + 1;
+  const int nwin = S1 - R + 1;
+  const float* pyc = py_grad + (size_t)b * S1 * T + t;
+  const float* pxc = px_grad + (size_t)b * S * T1 + t;
+  constexpr int CHK = 16;
+  // v[i] of a chunk starting at window c0 is py_grad row c0 + i (i < CHK + R): rows c0 .. c0+R-1 come from the previous
+  // chunk's tail (`carry`), rows c0+R .. c0+CHK+R-1 are loaded (the "lead" rows of this chunk's windows)
+  float carry[R];
+  float lead = 0.0f, lag = 0.0f;
+#pragma unroll
+  for (int s = 0; s < R; ++s) { carry[s] = pyc[(size_t)s * T]; }
+#pragma unroll
+  for (int s = 0; s < R; ++s) lead = lead + carry[s];
+  int best = 0;
+  float bestv = 0.0f;
+  float nv[2][CHK], xv[2][CHK];
+  auto fetch = [&](int c0, float (&n)[CHK], float (&x)[CHK]) {
+#pragma unroll
+    for (int u = 0; u < CHK; ++u) {
+      const int s0 = c0 + u;
+      n[u] = (s0 + 1 < nwin) ? pyc[(size_t)(s0 + R) * T] : 0.0f;
+      x[u] = (s0 > 0 && s0 < nwin) ? pxc[(size_t)(s0 - 1) * T1] : 0.0f;
+    }
+  };
+  auto consume = [&](int c0, const float (&n)[CHK], const float (&x)[CHK]) {
+#pragma unroll
+    for (int u = 0; u < CHK; ++u) {
+      const int s0 = c0 + u;
+      const float g = (u < R) ? carry[u < R ? u : 0] : n[u >= R ? u - R : 0];     // py_grad row s0
+      if (s0 < nwin) {
+        const float blk = lead - lag;                                      // rnnt_loss.py:725
+        const float fin = blk - x[u];                                      // :726-728 (px_pad[.,0] = 0)
+        if (s0 == 0 || fin > bestv) { best = s0; bestv = fin; }            // :729, first maximum
+        if (s0 + 1 < nwin) {
+          lead = lead + n[u];
+          lag = lag + g;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) carry[i] = n[CHK - R + i];                 // rows c0+CHK .. c0+CHK+R-1 for the next chunk
+  };
+  fetch(0, nv[0], xv[0]);
+  for (int c0 = 0; c0 < nwin; c0 += 2 * CHK) {
+    if (c0 + CHK < nwin) fetch(c0 + CHK, nv[1], xv[1]);
+    consume(c0, nv[0], xv[0]);
+    if (c0 + CHK < nwin) {
+      if (c0 + 2 * CHK < nwin) fetch(c0 + 2 * CHK, nv[0], xv[0]);
+      consume(c0 + CHK, nv[1], xv[1]);
+    }
+  }
+  const int se = boundary[4 * b + 2], te = boundary[4 * b + 3];
+  int pad = se - R + 1;                                                  // :744-746
+  if (pad < 0) pad = 0;
+  s_begin[(size_t)b * T + t] = (t < te - 1) ? best : pad;                // :741-748
+}
+
+// inclusive SUFFIX min-scan across the 64 lanes of a wave (lane l gets the minimum over lanes l..63)
+__device__ __forceinline__ int wave_incl_suffix_min(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_down(v, off, 64);
+    if (lane + off < 64) v = min(v, t);
+  }
+  return v;
+}
+
+// one wave per utterance, ONE right-to-left sweep over T in super-blocks of 1024 frames (16 consecutive frames per
+// lane, held in registers): suffix-min (rnnt_loss.py:628), x = -(x - (r-1) t) (:630-632), suffix-min again (:634),
+// clip at 0 (:636), transform back (:638-640), ranges write (:758-759).  Both scans run right to left, so the second
+// one can follow the first super-block by super-block with its own carry: no round trip through memory in between.
+__global__ void prune_adjust_kernel(const int32_t* __restrict__ s_begin, int32_t* __restrict__ ranges, int B,
                                     int T, int r_out, int r_con) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= B) return;
-  int32_t* x = s_begin + (size_t)b * T;
-  const int nblk = (T + 63) / 64;
-  // pass 1: suffix-min (rnnt_loss.py:628), then x = -(x - (r-1) t) (:630-632)
-  int carry = INT_MAX;
-  for (int blk = nblk - 1; blk >= 0; --blk) {
-    const int t = blk * 64 + (63 - lane);  // lane 0 holds the right-most column of the block
-    int v = (t < T) ? x[t] : INT_MAX;
-    v = wave_incl_min_scan(v, lane);
-    v = min(v, carry);
-    carry = __shfl(v, 63, 64);
-    if (t < T) x[t] = -(v - (r_con - 1) * t);
-  }
-  // pass 2 re-reads, in each lane, exactly the elements that lane wrote in pass 1 (same t mapping)
-  // pass 2: suffix-min (:634), clip at 0 (:636), transform back (:638-640), write ranges (:758-759)
-  carry = INT_MAX;
-  for (int blk = nblk - 1; blk >= 0; --blk) {
-    const int t = blk * 64 + (63 - lane);
-    int v = (t < T) ? x[t] : INT_MAX;
-    v = wave_incl_min_scan(v, lane);
-    v = min(v, carry);
-    carry = __shfl(v, 63, 64);
-    if (t < T) {
-      const int z = max(v, 0);
-      const int sb = -(z - (r_con - 1) * t);
-      int32_t* dst = ranges + ((size_t)b * T + t) * r_out;
-      for (int k = 0; k < r_out; ++k) dst[k] = sb + k;
+  constexpr int PER = 16, SB = 64 * PER;
+  const int32_t* x = s_begin + (size_t)b * T;
+  int carry1 = INT_MAX, carry2 = INT_MAX;
+  for (int base = ((T - 1) / SB) * SB; base >= 0; base -= SB) {
+    const int t0 = base + lane * PER;
+    int v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = (t0 + i < T) ? x[t0 + i] : INT_MAX;
+    // pass 1
+#pragma unroll
+    for (int i = PER - 2; i >= 0; --i) v[i] = min(v[i], v[i + 1]);
+    int incl = wave_incl_suffix_min(v[0], lane);              // lanes l..63 of this super-block
+    int right = __shfl_down(incl, 1, 64);                     // lanes l+1..63
+    right = (lane == 63) ? carry1 : min(right, carry1);
+    carry1 = min(__shfl(incl, 0, 64), carry1);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = t0 + i;
+      v[i] = (t < T) ? -(min(v[i], right) - (r_con - 1) * t) : INT_MAX;
+    }
+    // pass 2
+#pragma unroll
+    for (int i = PER - 2; i >= 0; --i) v[i] = min(v[i], v[i + 1]);
+    incl = wave_incl_suffix_min(v[0], lane);
+    right = __shfl_down(incl, 1, 64);
+    right = (lane == 63) ? carry2 : min(right, carry2);
+    carry2 = min(__shfl(incl, 0, 64), carry2);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int t = t0 + i;
+      if (t < T) {
+        const int z = max(min(v[i], right), 0);
+        const int sb = -(z - (r_con - 1) * t);
+        int32_t* dst = ranges + ((size_t)b * T + t) * r_out;
+        for (int k = 0; k < r_out; ++k) dst[k] = sb + k;
+      }
     }
   }
 }
@@ -540,8 +630,15 @@ int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boun
                  int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st) {
   if (B == 0 || T == 0) return FTR_OK;
   const int threads = 64;  // small blocks: B*T threads is only ~32k at the headline shape, spread them
-  hipLaunchKernelGGL(prune_argmax_kernel, dim3((T + threads - 1) / threads, B), dim3(threads), 0, st,
-                     px_grad, py_grad, boundary, s_begin, B, S, T, T1, r);
+  const dim3 grid((T + threads - 1) / threads, B);
+#define FTR_ARGMAX_ONCE(R) case R: hipLaunchKernelGGL(prune_argmax_once_kernel<R>, grid, dim3(threads), 0, st, px_grad, py_grad, boundary, s_begin, B, S, T, T1); break;
+  switch (r) {   // window lengths up to 16: py_grad is loaded once; longer windows: the generic kernel
+    FTR_ARGMAX_ONCE(1) FTR_ARGMAX_ONCE(2) FTR_ARGMAX_ONCE(3) FTR_ARGMAX_ONCE(4) FTR_ARGMAX_ONCE(5) FTR_ARGMAX_ONCE(6)
+    FTR_ARGMAX_ONCE(7) FTR_ARGMAX_ONCE(8) FTR_ARGMAX_ONCE(9) FTR_ARGMAX_ONCE(10) FTR_ARGMAX_ONCE(11) FTR_ARGMAX_ONCE(12)
+    FTR_ARGMAX_ONCE(13) FTR_ARGMAX_ONCE(14) FTR_ARGMAX_ONCE(15) FTR_ARGMAX_ONCE(16)
+    default: hipLaunchKernelGGL(prune_argmax_kernel, grid, dim3(threads), 0, st, px_grad, py_grad, boundary, s_begin, B, S, T, T1, r);
+  }
+#undef FTR_ARGMAX_ONCE
   int rc = check_launch("prune_argmax");
   if (rc != FTR_OK) return rc;
   const int r_con = (T1 == T) ? 2 : r;  // rnnt_loss.py:756
