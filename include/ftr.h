@@ -275,6 +275,26 @@ int ftr_simple_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, co
                                           const int32_t* symbols, const int32_t* boundary, int termination_symbol,
                                           float* d_am, int B, int T, int S, int C, int modified, void* stream);
 
+/* The smoothed loss as one node (rnnt_loss_smoothed, rnnt_loss.py:1369-1494, without framework-side passes over the
+ * lattices): the smoothed builder with the delay-penalty block (rnnt_loss.py:1461-1478) folded in, and the _scaled forms
+ * of its two lattice-reading backward kernels (upstream gradient applied on the fly, see the simple-loss forms above). */
+int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                                      const float* am_max, const float* lm_max, const float* lmonly_norm,
+                                      const float* amonly_norm, const float* unigram_log, const int32_t* boundary,
+                                      int termination_symbol, double delay_penalty, float combined_scale,
+                                      float lm_only_scale, float am_only_scale, float* px, float* py, int B, int T,
+                                      int S, int C, int modified, void* stream);
+int ftr_smoothed_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                           float scale_mul, const float* prod, const int32_t* boundary,
+                                           float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,
+                                           int modified, void* stream);
+int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                            float scale_mul, const float* damp, const float* am_probs,
+                                            const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                            float direct_scale, const float* unigram, const float* am_dot,
+                                            float am_only_scale, float* R, float* d_am, int B, int T, int S, int C,
+                                            int modified, void* stream);
+
 /* Hardware self-test used by smoke()/tests: checks on the device that the primitives the wavefront
  * kernels rely on behave as assumed (full-wave DPP shift wave_shr:1 with lane 0 keeping its old value;
  * 16-byte global loads/stores at 4-byte alignment).  scratch_dev: >= 8 KiB of device memory; after the

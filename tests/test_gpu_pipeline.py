@@ -429,6 +429,40 @@ def test_fused_loss_nodes_match_composed_path(ft, dev, reduction, rnnt_type):
     assert max_rel(a[2], b[2]) <= 1e-5 and max_rel(a[3], b[3]) <= 1e-5
 
 
+@pytest.mark.parametrize("reduction", ["none", "mean", "sum"])
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
+def test_fused_smoothed_loss_matches_composed_path(ft, dev, reduction, rnnt_type):
+    """rnnt_loss_smoothed as a single autograd node (penalty inside the builder kernel, ftr_smoothed_logprobs_bwd_*_scaled)
+    against the same loss composed from get_rnnt_logprobs_smoothed -> penalty -> mutual_information_recursion -> torch
+    reduction: value, occupancies and d/d am, d/d lm with a non-trivial upstream gradient.  Same kernels: 1e-5."""
+    from tf_fast_rnnt.rnnt_loss import _apply_delay_penalty, _reduce
+    d = synthetic(43, 3, 31, 8, 14, ragged=True)
+    sym = _t(d["symbols"], dev); bd = _t(d["boundary"], dev); blank = d["termination_symbol"]
+    wgt = torch.rand((3,), generator=torch.Generator(device="cpu").manual_seed(5)).to(dev) + 0.5
+
+    def run(fused):
+        am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+        if fused:
+            loss, (gx, gy) = ft.rnnt_loss_smoothed(lm, am, sym, blank, 0.1, 0.2, bd, rnnt_type, 0.15, reduction, True)
+        else:
+            px, py = ft.get_rnnt_logprobs_smoothed(lm, am, sym, blank, 0.1, 0.2, bd, rnnt_type)
+            px = _apply_delay_penalty(px, bd, rnnt_type, 0.15)
+            ans, (gx, gy) = ft.mutual_information_recursion(px, py, bd, True)
+            loss = _reduce(ans, reduction)
+        total = (loss * wgt).sum() if reduction == "none" else 1.7 * loss
+        total.backward()
+        return loss.detach().cpu().numpy(), gx.cpu().numpy(), gy.cpu().numpy(), am.grad.cpu().numpy(), lm.grad.cpu().numpy()
+
+    a = run(True); b = run(False)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
+    for i in (1, 2, 3, 4):
+        assert max_rel(a[i], b[i]) <= 1e-5, i
+    # no occupancies wanted, no autograd: the recursion backward is skipped and zeros are returned
+    with torch.no_grad():
+        only = ft.rnnt_loss_smoothed(_t(d["lm"], dev), _t(d["am"], dev), sym, blank, 0.1, 0.2, bd, rnnt_type, 0.15, reduction)
+    np.testing.assert_allclose(only.cpu().numpy(), a[0], rtol=1e-6)
+
+
 def test_out_of_range_caller_data_does_not_fault(ft, dev):
     """Malformed boundary rows, symbols and ranges (caller data the reference never validates) must not send a kernel
     out of bounds: boundaries are clamped into the lattice, symbols into the vocabulary, gather rows into lm; rows of

@@ -431,6 +431,53 @@ int ftr_simple_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, co
   return simple_logprobs_bwd_am(gpx, gpy, Scale{scale, scale_stride, scale_mul}, damp, am_probs, symbols, boundary, termination_symbol, 1.0f, nullptr, nullptr, 0.0f, nullptr, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
+                                      const float* am_max, const float* lm_max, const float* lmonly_norm,
+                                      const float* amonly_norm, const float* unigram_log, const int32_t* boundary,
+                                      int termination_symbol, double delay_penalty, float combined_scale,
+                                      float lm_only_scale, float am_only_scale, float* px, float* py, int B, int T,
+                                      int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "smoothed_logprobs_fwd_pen: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_fwd_pen: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(am && lm && prod && am_max && lm_max && lmonly_norm && amonly_norm && unigram_log && py && (symbols || S == 0) && (px || S == 0), "smoothed_logprobs_fwd_pen: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_fwd(am, lm, symbols, prod, am_max, lm_max, boundary, termination_symbol, delay_penalty, lmonly_norm, amonly_norm, unigram_log, combined_scale, lm_only_scale, am_only_scale, px, py, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                           float scale_mul, const float* prod, const int32_t* boundary,
+                                           float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,
+                                           int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0, "smoothed_logprobs_bwd_w_scaled: bad sizes");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "smoothed_logprobs_bwd_w_scaled: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && prod && W && rsx && rsy && (gpx || S == 0), "smoothed_logprobs_bwd_w_scaled: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_w(gpx, gpy, Scale{scale, scale_stride, scale_mul}, prod, boundary, W, rsx, rsy, combined_scale, B, T, S, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                            float scale_mul, const float* damp, const float* am_probs,
+                                            const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                            float direct_scale, const float* unigram, const float* am_dot,
+                                            float am_only_scale, float* R, float* d_am, int B, int T, int S, int C,
+                                            int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "smoothed_logprobs_bwd_am_scaled: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_bwd_am_scaled: bad termination_symbol");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "smoothed_logprobs_bwd_am_scaled: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && damp && am_probs && d_am && unigram && am_dot && R && (gpx || S == 0) && (symbols || S == 0), "smoothed_logprobs_bwd_am_scaled: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_logprobs_bwd_am(gpx, gpy, Scale{scale, scale_stride, scale_mul}, damp, am_probs, symbols, boundary, termination_symbol, direct_scale, unigram, am_dot, am_only_scale, R, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ftr_selftest(void* scratch_dev, void* stream) {
   clear_error();
   FTR_REQUIRE(scratch_dev, "selftest: need >= 8 KiB of device scratch");

@@ -608,6 +608,92 @@ def rnnt_loss_pruned(
                              float(delay_penalty) if delay_penalty > 0.0 else 0.0, code)
 
 
+def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale, am_only_scale,
+                      process_group, delay_penalty):
+    """Forward of the smoothed builder on the native kernels (rnnt_loss.py:1265-1365; with the penalty block :1461-1478
+    folded into the lattice writer when delay_penalty > 0).  Returns px, py and what the backward needs."""
+    B, T, C = am.shape
+    S = lm.shape[1] - 1
+    T1 = T if modified else T + 1
+    cs = 1.0 - lm_only_scale - am_only_scale                    # :1342
+    ls = lm_only_scale if lm_only_scale != 0.0 else 1.0e-20       # :1346-1349
+    a_s = am_only_scale if am_only_scale != 0.0 else 1.0e-20
+    amc = am.detach().contiguous(); lmc = lm.detach().contiguous()
+    dev = amc.device
+    am_probs = torch.empty_like(amc); lm_probs = torch.empty_like(lmc)
+    am_max = torch.empty((B, T), dtype=torch.float32, device=dev)
+    lm_max = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+    lm_sum = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+    px = torch.empty((B, S, T1), dtype=torch.float32, device=dev)
+    py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _stream_ptr(amc)
+        _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)           # :1265-1268
+        _lib.call("ftr_rowmax_exp_sum_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), _ptr(lm_sum),
+                  B * (S + 1), C, st)                                                                   # :1276-1278
+        prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                            # :1270-1272
+        inv = 1.0 / lm_sum                                                                              # [B,S+1]
+        ratio_sum = torch.mv(lm_probs.reshape(-1, C).t(), inv.reshape(-1))                               # [C]
+        count = float(B * (S + 1))
+        if process_group is not None:
+            torch.distributed.all_reduce(ratio_sum, group=process_group)
+            count *= torch.distributed.get_world_size(process_group)
+        u = ratio_sum / count + _TINY                                                                   # :1279-1280
+        am_dot = torch.mv(am_probs.reshape(-1, C), u)                                                   # [B*T]
+        amonly = (am_dot.log().reshape(B, T) + am_max).contiguous()                                     # :1281-1286
+        ulog = u.log().contiguous()                                                                     # :1287
+        lmonly = (lm_sum.log() + lm_max).contiguous()                                                   # :1288-1290
+        _lib.call("ftr_smoothed_logprobs_fwd_pen_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
+                  _ptr(lm_max), _ptr(lmonly), _ptr(amonly), _ptr(ulog), _ptr(boundary), int(termination_symbol),
+                  float(delay_penalty), cs, ls, a_s, _ptr(px), _ptr(py), B, T, S, C, int(modified), st)
+    saved = (am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0), inv, u, am_dot)
+    meta = (int(termination_symbol), int(modified), cs, ls, a_s, count, process_group)
+    return px, py, saved, meta
+
+
+def _smoothed_backward(saved, has_boundary, meta, gpx, gpy, scale=None, stride=0, mul=1.0):
+    """Hand-written backward of the smoothed builder; gpx / gpy are d/d px, d/d py, multiplied on the fly by
+    (scale ? scale[b * stride] : 1) * mul (the upstream gradient of the loss that owns the occupancies)."""
+    am_probs, lm_probs, prod, symbols, boundary, inv, u, am_dot = saved
+    if not has_boundary:
+        boundary = None
+    blank, modified, cs, ls, a_s, count, group = meta
+    B, T, C = am_probs.shape
+    S = lm_probs.shape[1] - 1
+    dev = am_probs.device
+    gpx = gpx.contiguous(); gpy = gpy.contiguous()
+    W = torch.empty_like(prod)
+    rsx = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+    rsy = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+    R = torch.empty((B, T), dtype=torch.float32, device=dev)
+    d_am = torch.empty_like(am_probs); d_lm = torch.empty_like(lm_probs)
+    with torch.cuda.device(dev):
+        st = _stream_ptr(am_probs)
+        _lib.call("ftr_smoothed_logprobs_bwd_w_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
+                  _ptr(boundary), cs, _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
+        dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+        damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
+        _lib.call("ftr_smoothed_logprobs_bwd_am_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(damp),
+                  _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R),
+                  _ptr(d_am), B, T, S, C, modified, st)
+        # d u: through amonly_norm and through ulog
+        du = torch.mv(am_probs.reshape(-1, C).t(), R.reshape(-1))
+        gul = torch.zeros((C,), dtype=torch.float32, device=dev)
+        if S > 0:
+            gul.index_add_(0, _i64(symbols).reshape(-1), rsx[:, :S].reshape(-1))
+        gul[blank] += rsy.sum()
+        du = du + a_s * gul / u
+        if group is not None:
+            torch.distributed.all_reduce(du, group=group)
+        gu = (du / count).contiguous()
+        dotq = torch.mv(lm_probs.reshape(-1, C), gu).reshape(B, S + 1) * inv
+        arow = ((-ls) * (rsx + rsy) - dotq) * inv
+        arow = arow.contiguous()
+        _lib.call("ftr_smoothed_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx),
+                  _ptr(rsy), blank, cs + ls, _ptr(arow), _ptr(inv), _ptr(gu), _ptr(d_lm), B, S, C, st)
+    return d_lm, d_am
+
+
 class _SmoothedLogprobs(torch.autograd.Function):
     """get_rnnt_logprobs_smoothed (+ fix_for_boundary) for regular/modified on the native builder kernels.
 
@@ -629,86 +715,50 @@ class _SmoothedLogprobs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale, am_only_scale,
                 process_group):
-        B, T, C = am.shape
-        S = lm.shape[1] - 1
-        T1 = T if modified else T + 1
-        cs = 1.0 - lm_only_scale - am_only_scale                    # :1342
-        ls = lm_only_scale if lm_only_scale != 0.0 else 1.0e-20       # :1346-1349
-        a_s = am_only_scale if am_only_scale != 0.0 else 1.0e-20
-        amc = am.detach().contiguous(); lmc = lm.detach().contiguous()
-        dev = amc.device
-        am_probs = torch.empty_like(amc); lm_probs = torch.empty_like(lmc)
-        am_max = torch.empty((B, T), dtype=torch.float32, device=dev)
-        lm_max = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
-        lm_sum = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
-        px = torch.empty((B, S, T1), dtype=torch.float32, device=dev)
-        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            st = _stream_ptr(amc)
-            _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)           # :1265-1268
-            _lib.call("ftr_rowmax_exp_sum_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), _ptr(lm_sum),
-                      B * (S + 1), C, st)                                                                   # :1276-1278
-            prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                            # :1270-1272
-            inv = 1.0 / lm_sum                                                                              # [B,S+1]
-            ratio_sum = torch.mv(lm_probs.reshape(-1, C).t(), inv.reshape(-1))                               # [C]
-            count = float(B * (S + 1))
-            if process_group is not None:
-                torch.distributed.all_reduce(ratio_sum, group=process_group)
-                count *= torch.distributed.get_world_size(process_group)
-            u = ratio_sum / count + _TINY                                                                   # :1279-1280
-            am_dot = torch.mv(am_probs.reshape(-1, C), u)                                                   # [B*T]
-            amonly = (am_dot.log().reshape(B, T) + am_max).contiguous()                                     # :1281-1286
-            ulog = u.log().contiguous()                                                                     # :1287
-            lmonly = (lm_sum.log() + lm_max).contiguous()                                                   # :1288-1290
-            _lib.call("ftr_smoothed_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
-                      _ptr(lm_max), _ptr(lmonly), _ptr(amonly), _ptr(ulog), _ptr(boundary), int(termination_symbol),
-                      cs, ls, a_s, _ptr(px), _ptr(py), B, T, S, C, int(modified), st)
-        ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0),
-                              inv, u, am_dot)
+        px, py, saved, meta = _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale,
+                                                am_only_scale, process_group, 0.0)
+        ctx.save_for_backward(*saved)
         ctx.has_boundary = boundary is not None
-        ctx.meta = (int(termination_symbol), int(modified), cs, ls, a_s, count, process_group)
+        ctx.meta = meta
         return px, py
 
     @staticmethod
     def backward(ctx, gpx, gpy):
-        am_probs, lm_probs, prod, symbols, boundary, inv, u, am_dot = ctx.saved_tensors
-        if not ctx.has_boundary:
-            boundary = None
-        blank, modified, cs, ls, a_s, count, group = ctx.meta
-        B, T, C = am_probs.shape
-        S = lm_probs.shape[1] - 1
-        dev = am_probs.device
-        gpx = gpx.contiguous(); gpy = gpy.contiguous()
-        W = torch.empty_like(prod)
-        rsx = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
-        rsy = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
-        R = torch.empty((B, T), dtype=torch.float32, device=dev)
-        d_am = torch.empty_like(am_probs); d_lm = torch.empty_like(lm_probs)
-        with torch.cuda.device(dev):
-            st = _stream_ptr(am_probs)
-            _lib.call("ftr_smoothed_logprobs_bwd_w_f32", _ptr(gpx), _ptr(gpy), _ptr(prod), _ptr(boundary), cs, _ptr(W),
-                      _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
-            dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-            damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
-            _lib.call("ftr_smoothed_logprobs_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(damp), _ptr(am_probs),
-                      _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R), _ptr(d_am),
-                      B, T, S, C, modified, st)
-            # d u: through amonly_norm and through ulog
-            du = torch.mv(am_probs.reshape(-1, C).t(), R.reshape(-1))
-            gul = torch.zeros((C,), dtype=torch.float32, device=dev)
-            if S > 0:
-                gul.index_add_(0, _i64(symbols).reshape(-1), rsx[:, :S].reshape(-1))
-            gul[blank] += rsy.sum()
-            du = du + a_s * gul / u
-            if group is not None:
-                torch.distributed.all_reduce(du, group=group)
-            gu = (du / count).contiguous()
-            dotq = torch.mv(lm_probs.reshape(-1, C), gu).reshape(B, S + 1) * inv
-            arow = ((-ls) * (rsx + rsy) - dotq) * inv
-            arow = arow.contiguous()
-            _lib.call("ftr_smoothed_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx),
-                      _ptr(rsy), blank, cs + ls, _ptr(arow), _ptr(inv), _ptr(gu), _ptr(d_lm), B, S, C, st)
+        d_lm, d_am = _smoothed_backward(ctx.saved_tensors, ctx.has_boundary, ctx.meta, gpx, gpy)
         return d_lm, d_am, None, None, None, None, None, None, None
+
+
+class _SmoothedLoss(torch.autograd.Function):
+    """rnnt_loss_smoothed for regular/modified as ONE graph node, like _SimpleLoss: smoothed builder (penalty folded
+    in) + GEMM, recursion forward + backward (occupancies), native loss reduction; backward() feeds the occupancies to
+    the builder's backward kernels with the upstream gradient folded in on the fly."""
+
+    @staticmethod
+    def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale, am_only_scale,
+                process_group, delay_penalty, code, want_occupancies):
+        px, py, saved, meta = _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale,
+                                                am_only_scale, process_group, delay_penalty)
+        need = bool(want_occupancies) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
+        loss = _negated_reduce_native(ans, code)
+        if need:
+            ctx.save_for_backward(*saved, px_grad, py_grad)
+        else:
+            px_grad = torch.zeros_like(px); py_grad = torch.zeros_like(py)
+        del px, py
+        ctx.has_boundary = boundary is not None
+        ctx.meta = meta
+        ctx.code = int(code)
+        ctx.mark_non_differentiable(px_grad, py_grad)
+        return loss, px_grad, py_grad
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):
+        *saved, px_grad, py_grad = ctx.saved_tensors
+        B = saved[0].shape[0]
+        scale, stride, mul = _upstream_scale(g_loss, ctx.code, B)
+        d_lm, d_am = _smoothed_backward(tuple(saved), ctx.has_boundary, ctx.meta, px_grad, py_grad, scale, stride, mul)
+        return d_lm, d_am, None, None, None, None, None, None, None, None, None, None
 
 
 def get_rnnt_logprobs_smoothed(
@@ -762,10 +812,19 @@ def rnnt_loss_smoothed(
     calc_gradients: bool = False,
     process_group=None,
 ) -> Union[Tuple[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]], torch.Tensor]:
-    """rnnt_loss.py:1369-1494."""
+    """rnnt_loss.py:1369-1494.  regular / modified: one fused node (no framework-side pass over a lattice)."""
+    _check_type(rnnt_type)
     boundary = _as_boundary(boundary, am.shape[0], am.device)
-    px, py = get_rnnt_logprobs_smoothed(lm=lm, am=am, symbols=symbols, termination_symbol=termination_symbol,
-                                        lm_only_scale=lm_only_scale, am_only_scale=am_only_scale,
-                                        boundary=boundary, rnnt_type=rnnt_type, process_group=process_group)
-    px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
-    return _drive(px, py, boundary, reduction, calc_gradients)
+    if rnnt_type == "constrained":   # the penalty applies after px += py[:, 1:, :]  (:1362-1363, :1461-1478)
+        px, py = get_rnnt_logprobs_smoothed(lm=lm, am=am, symbols=symbols, termination_symbol=termination_symbol,
+                                            lm_only_scale=lm_only_scale, am_only_scale=am_only_scale,
+                                            boundary=boundary, rnnt_type=rnnt_type, process_group=process_group)
+        px = _apply_delay_penalty(px, boundary, rnnt_type, delay_penalty)
+        return _drive(px, py, boundary, reduction, calc_gradients)
+    code = _reduction_code(reduction)
+    symbols_i = _check_simple_inputs(lm, am, symbols, termination_symbol)
+    pen = float(delay_penalty) if delay_penalty > 0.0 else 0.0
+    loss, px_grad, py_grad = _SmoothedLoss.apply(lm, am, symbols_i, termination_symbol, boundary, rnnt_type != "regular",
+                                                 float(lm_only_scale), float(am_only_scale), process_group, pen, code,
+                                                 bool(calc_gradients))
+    return (loss, (px_grad, py_grad)) if calc_gradients else loss
