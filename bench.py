@@ -141,6 +141,9 @@ CALL_KERNELS = {
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
     "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_chunk_kernel<true>", "do_pruning_bwd_reduce_kernel"],
     "ftr_pruned_logprobs_fwd_f32": ["lse_rows_kernel<true>", "band_to_lattice_kernel<false>"],
+    "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_gather_kernel<false>"],
+    "ftr_mutual_information_band_f32": ["mi_band_kernel<false>"],
+    "ftr_pruned_band_bwd_scaled_f32": ["band_grad_banded_kernel<true>"],
     "ftr_pruned_logprobs_bwd_f32": ["band_grad_kernel<false, true>"],
     "ftr_pruned_logprobs_bwd_scaled_f32": ["band_grad_kernel<false, true>"],
     "ftr_simple_logprobs_bwd_w_scaled_f32": ["simple_bwd_w_kernel<false>"],
@@ -200,6 +203,10 @@ def algorithmic_bytes(B, T, S, C, r):
         "ftr_prune_ranges_i32": 4 * (npx + npy + B * T * r),
         "ftr_do_pruning_f32": 4 * (B * T * C + B * (S + 1) * C + B * T * r) + 2 * N,
         "ftr_pruned_logprobs_fwd_f32": N + 4 * (npx + npy),              # stream logits once, write px,py
+        # the band path of rnnt_loss_pruned (3 N + O(B T r) for the pruned loss with a banded DP)
+        "ftr_pruned_band_fwd_f32": N + 4 * 3 * B * T * r,                # stream logits once; lse, px_band, py_band
+        "ftr_mutual_information_band_f32": 4 * 5 * B * T * r,            # band in, occupancies out (lives in LDS in between)
+        "ftr_pruned_band_bwd_scaled_f32": 2 * N + 4 * 3 * B * T * r,     # re-read logits, write the gradient
         "ftr_pruned_logprobs_bwd_f32": 2 * N + 4 * (npx + npy),          # re-read logits, write the gradient
     }
 

@@ -295,6 +295,35 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
                                             float am_only_scale, float* R, float* d_am, int B, int T, int S, int C,
                                             int modified, void* stream);
 
+/*
+ * The pruned loss on the band itself.  rnnt_loss_pruned (rnnt_loss.py:1022-1130) pads the band [B,T,r] to full-size px / py
+ * lattices (rnnt_loss.py:968-1013) and runs the whole (S+1) x (T+1) recursion on them; these three entry points keep
+ * everything band shaped ([B,T,r]; row (b,t,k) <-> lattice cell (ranges[b,t,0] + k, t)):
+ *   ftr_pruned_band_fwd_f32           lse [B,T,r] (rnnt_loss.py:942) and px_band / py_band = the values the full-size
+ *                                     lattices would hold at the band cells (-inf rules and delay penalty included)
+ *   ftr_mutual_information_band_f32   forward recursion, cut, backward recursion in ONE launch (one wave per utterance,
+ *                                     LDS resident): ans [B] and the occupancies gx_band / gy_band (= px_grad / py_grad
+ *                                     at the band cells, seed = ones)
+ *   ftr_pruned_band_bwd_scaled_f32    d loss / d logits from the band-shaped occupancies (the _scaled semantics above)
+ * PRECONDITION on `ranges` (what get_rnnt_prune_ranges produces; not checked on the device): for every utterance
+ * ranges[b,t,0] is non-decreasing in t, grows by at most r - 1 per frame (at most 1 for the modified type), and
+ * 0 <= ranges[b,t,0] <= S - r + 1.  Callers with arbitrary ranges use ftr_pruned_logprobs_* + the lattice recursion.
+ * ftr_mutual_information_band_supported() says whether (T, S, r) fits the LDS-resident kernel (r <= 16 and about
+ * 12 T r + 4 T bytes <= 150 KB); ftr_mutual_information_band_f32 returns FTR_ERR_UNSUPPORTED otherwise.
+ */
+int ftr_mutual_information_band_supported(int T, int S, int r);
+int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
+                            int termination_symbol, double delay_penalty, float* lse, float* px_band, float* py_band,
+                            int B, int T, int S, int C, int r, int modified, void* stream);
+int ftr_mutual_information_band_f32(const float* px_band, const float* py_band, const int32_t* ranges,
+                                    const int32_t* boundary, float* ans, float* gx_band, float* gy_band, int B, int T,
+                                    int S, int r, int modified, void* stream);
+int ftr_pruned_band_bwd_scaled_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                   const int32_t* boundary, int termination_symbol, const float* lse,
+                                   const float* gx_band, const float* gy_band, const float* scale, int scale_stride,
+                                   float scale_mul, float* glogits, int B, int T, int S, int C, int r, int modified,
+                                   void* stream);
+
 /* Hardware self-test used by smoke()/tests: checks on the device that the primitives the wavefront
  * kernels rely on behave as assumed (full-wave DPP shift wave_shr:1 with lane 0 keeping its old value;
  * 16-byte global loads/stores at 4-byte alignment).  scratch_dev: >= 8 KiB of device memory; after the

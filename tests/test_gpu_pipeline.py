@@ -463,6 +463,41 @@ def test_fused_smoothed_loss_matches_composed_path(ft, dev, reduction, rnnt_type
     np.testing.assert_allclose(only.cpu().numpy(), a[0], rtol=1e-6)
 
 
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
+@pytest.mark.parametrize("cfg", [(3, 40, 12, 20, 4), (2, 90, 33, 12, 5), (4, 64, 20, 16, 2), (2, 130, 50, 24, 8), (2, 70, 40, 8, 16),
+                                 (3, 33, 5, 7, 3), (2, 200, 50, 50, 5), (1, 300, 10, 16, 11), (2, 25, 20, 8, 6)])
+def test_band_native_pruned_loss_matches_lattice_path(ft, dev, oracle, rnnt_type, cfg):
+    """rnnt_loss_pruned on the band itself (ftr_mutual_information_band_f32: ranges carrying get_rnnt_prune_ranges' mark)
+    against the same loss through full-size lattices (an unmarked copy of the same ranges): loss and d/d logits, ragged
+    boundaries, delay penalty, non-trivial upstream gradient.  Two float32 evaluations of the same quantity: 1e-4 on the
+    loss, 2e-4 normwise on the gradient (observed ~1e-6 / ~1e-5); and both against the float64 oracle."""
+    B, T, S, C, r = cfg
+    d = synthetic(100 + T + S, B, T, S, C, ragged=True)
+    blank = d["termination_symbol"]
+    am, lm, sym, bd = (_t(d[k], dev) for k in ("am", "lm", "symbols", "boundary"))
+    _, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, rnnt_type, reduction="sum", calc_gradients=True)
+    ranges = ft.get_rnnt_prune_ranges(gx, gy, bd, r)
+    assert getattr(ranges, "_ftr_monotone", False)
+    am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
+    base = torch.tanh(am_p + lm_p).detach()
+    wgt = torch.rand((B,), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev) + 0.5
+    outs = []
+    for rg in (ranges, ranges.clone()):
+        logits = base.clone().requires_grad_(True)
+        loss = ft.rnnt_loss_pruned(logits, sym, rg, blank, bd, rnnt_type, 0.1, "none")
+        (loss * wgt).sum().backward()
+        outs.append((loss.detach().cpu().numpy(), logits.grad.cpu().numpy()))
+    fin = np.isfinite(outs[1][0])
+    assert np.array_equal(np.isfinite(outs[0][0]), fin)
+    np.testing.assert_allclose(outs[0][0][fin], outs[1][0][fin], rtol=1e-4)
+    assert max_rel(outs[0][1][fin], outs[1][1][fin]) <= 2e-4
+    if rnnt_type == "regular":
+        o_loss, o_g = oracle.rnnt_loss_pruned_grad(base.cpu().numpy(), d["symbols"], ranges.cpu().numpy(), blank, d["boundary"],
+                                                   delay_penalty=0.1, reduction="none", dtype=np.float64)
+        np.testing.assert_allclose(outs[0][0][fin], o_loss[fin], rtol=1e-4)
+        assert max_rel(outs[0][1][fin], (o_g * wgt.cpu().numpy().reshape(-1, 1, 1, 1))[fin]) <= 2e-4
+
+
 def test_out_of_range_caller_data_does_not_fault(ft, dev):
     """Malformed boundary rows, symbols and ranges (caller data the reference never validates) must not send a kernel
     out of bounds: boundaries are clamped into the lattice, symbols into the vocabulary, gather rows into lm; rows of

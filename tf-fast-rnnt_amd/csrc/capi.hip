@@ -478,6 +478,52 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
   return simple_logprobs_bwd_am(gpx, gpy, Scale{scale, scale_stride, scale_mul}, damp, am_probs, symbols, boundary, termination_symbol, direct_scale, unigram, am_dot, am_only_scale, R, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ftr_mutual_information_band_supported(int T, int S, int r) { return mi_band_supported(T, S, r); }
+
+int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
+                            int termination_symbol, double delay_penalty, float* lse, float* px_band, float* py_band,
+                            int B, int T, int S, int C, int r, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1 && r >= 1, "pruned_band_fwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "pruned_band_fwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(logits && ranges && lse && px_band && py_band && (symbols || S == 0), "pruned_band_fwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  rc = lse_rows(logits, lse, (size_t)B * T * r, C, st);
+  if (rc != FTR_OK) return rc;
+  return band_gather(logits, symbols, ranges, boundary, lse, termination_symbol, delay_penalty, px_band, py_band, B, T, S, C, r, modified, st);
+}
+
+int ftr_mutual_information_band_f32(const float* px_band, const float* py_band, const int32_t* ranges,
+                                    const int32_t* boundary, float* ans, float* gx_band, float* gy_band, int B, int T,
+                                    int S, int r, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && r >= 1, "mutual_information_band: bad sizes");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(px_band && py_band && ranges && ans && gx_band && gy_band, "mutual_information_band: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return mi_band(px_band, py_band, ranges, boundary, ans, gx_band, gy_band, B, T, S, r, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_pruned_band_bwd_scaled_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                                   const int32_t* boundary, int termination_symbol, const float* lse,
+                                   const float* gx_band, const float* gy_band, const float* scale, int scale_stride,
+                                   float scale_mul, float* glogits, int B, int T, int S, int C, int r, int modified,
+                                   void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1 && r >= 1, "pruned_band_bwd_scaled: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "pruned_band_bwd_scaled: bad termination_symbol");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "pruned_band_bwd_scaled: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(logits && ranges && lse && gx_band && gy_band && glogits && (symbols || S == 0), "pruned_band_bwd_scaled: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return band_grad_banded(logits, symbols, ranges, boundary, termination_symbol, lse, gx_band, gy_band, Scale{scale, scale_stride, scale_mul}, glogits, B, T, S, C, r, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ftr_selftest(void* scratch_dev, void* stream) {
   clear_error();
   FTR_REQUIRE(scratch_dev, "selftest: need >= 8 KiB of device scratch");

@@ -106,6 +106,11 @@ int simple_logprobs_bwd_w(const float* gpx, const float* gpy, Scale scale, const
 int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* damp, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
 int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx, const float* rsy, int blank, float kdir, const float* arow, const float* invsum, const float* gu, float* d_lm, int B, int S, int C, hipStream_t st);
 int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);
+int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st);
+int mi_band_supported(int T, int S, int r);
+int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, hipStream_t st);
+int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ans, float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st);
+int band_grad_banded(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gxb, const float* gyb, Scale scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int selftest(hipStream_t st, int* result_dev);
 int debug_stamps(unsigned long long* out16);
 int debug_trace(unsigned long long* out, int n);

@@ -1,0 +1,446 @@
+// csrc/mi_band.hip -- the recursion on the PRUNED band itself (gfx950): rnnt_loss_pruned without the full-size lattices.
+//
+// get_rnnt_logprobs_pruned (/root/reference/tf_fast_rnnt/python/tf_fast_rnnt/rnnt_loss.py:968-1013) pads the band
+// [B,T,r] to full-size px / py lattices that are > 97 % -inf and the op runs the whole (S+1) x (T+1) recursion on them.
+// Here the band arrays go into ONE launch that runs forward, cut reduction and backward for an utterance inside one
+// wave, entirely out of LDS:
+//
+//   band cell (t,k)  <->  lattice cell (s,t), s = s0[t] + k,  s0[t] = ranges[b,t,0]   (monotone, steps <= r-1: what
+//   get_rnnt_prune_ranges produces; the host only routes such ranges here)
+//
+// Wavefront over the band: the cells of one anti-diagonal (regular) / one column (modified) that lie inside the band
+// are at most r consecutive lattice rows (the band is monotone), so with LANES >= r lanes, lane (row mod LANES) owns at
+// most one cell per walk step, and both predecessors of a cell were computed one step earlier -- by the same lane
+// ((s,t-1)) and by the cyclically previous lane ((s-1,t) resp. (s-1,t-1): v_mov_b32_dpp row_ror:1).
+//
+// The chains themselves know nothing about bands: the parallel phases in front of them scatter the operands of every
+// band cell into WAVEFRONT ORDER, [walk step][lane], with every transition that does not exist, leaves the rectangle or
+// leaves the band already replaced by -inf, and slots without a cell filled with -inf.  Every lane then just computes
+//     v <- logadd(dpp(v) + OX[step][lane], v + OY[step][lane])
+// step after step, reading LDS at consecutive addresses two steps ahead of the dependent chain.
+//
+// Two chains per utterance, as in mi_wave_bidir.hip: chain A (DPP row 0) walks up from the origin, chain B (DPP row 1)
+// walks down from the end cell; each stores the split ratio G of its cells.  They meet on the cut (the middle
+// anti-diagonal / column), ans = logsumexp over the cut of p + q, and then each chain simply KEEPS WALKING through the
+// other half in "flow" mode: it injects the cut occupancies and pushes them on with the other chain's ratios, writing
+// the per-transition flows (= the occupancies px_grad / py_grad), which a last parallel phase stores band shaped.
+//
+// LDS (per utterance): lo[T+1] (band start per column) and three arrays of (S_n + T_n + 1) x LANES floats: OX, OY
+// (operands, later the two flow outputs) and G.  LANES = 8 while r <= 8, 16 up to r = 16.
+#include "ftr_common.h"
+#include <type_traits>
+
+namespace ftr {
+namespace {
+
+constexpr int kBandThreads = 512;   // eight waves for the parallel phases (staging, operands, store); the chains run in wave 0
+
+__device__ __forceinline__ float dpp_row_ror1(float v) {   // lane i of each 16-lane row receives lane (i-1) mod 16
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {      // all-reduce over the 16 lanes of a DPP row
+  v = fmaxf(v, dpp_row_ror<8>(v)); v = fmaxf(v, dpp_row_ror<4>(v));
+  v = fmaxf(v, dpp_row_ror<2>(v)); v = fmaxf(v, dpp_row_ror<1>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_row_ror<8>(v); v += dpp_row_ror<4>(v); v += dpp_row_ror<2>(v); v += dpp_row_ror<1>(v);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------- band gather
+// px_band[b,t,k] = px[b, s0+k, t], py_band[b,t,k] = py[b, s0+k, t] of get_rnnt_logprobs_pruned (rnnt_loss.py:942-1016)
+// + the delay-penalty block (:1097-1114): logits[row, symbol] - lse, -inf where the lattice has none (s >= S, the
+// boundary column of the regular type), one thread per band cell.
+template <bool MOD>
+__global__ void band_gather_kernel(const float* __restrict__ logits, const int32_t* __restrict__ symbols,
+                                   const int32_t* __restrict__ ranges, const int32_t* __restrict__ boundary,
+                                   const float* __restrict__ lse, int blank, double delay_penalty,
+                                   float* __restrict__ pxb, float* __restrict__ pyb, size_t rows, int T, int S, int C, int r) {
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const size_t bt = row / r;
+  const int k = (int)(row - bt * r);
+  const int b = (int)(bt / T);
+  const int t = (int)(bt - (size_t)b * T);
+  const int s = ranges[bt * r] + k;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const float l = lse[row];
+  float vy = -INFINITY, vx = -INFINITY;
+  if (s >= 0 && s <= S) {
+    vy = logits[row * C + blank] - l;
+    if (s < S) {
+      vx = logits[row * C + min(max(symbols[(size_t)b * S + s], 0), C - 1)] - l;
+      if (!MOD && t == te) vx = -INFINITY;
+      if (delay_penalty > 0.0) vx += (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty);
+    }
+  }
+  pxb[row] = vx;
+  pyb[row] = vy;
+}
+
+// ---------------------------------------------------------------------------------------- the band recursion
+// Wavefront-ordered arrays, [row][lane], LANES lanes per row:
+//   row 0                  pad (G = 0): where the shorter flow walk takes its one surplus step
+//   rows 1 .. jm+1         chain A's steps: cell (s,t) at step (s-sb)+(t-tb) [modified: t-tb], lane (s-sb) mod LANES
+//   row jm+2               pad (OX = -inf, OY = 0: a step that leaves the value unchanged), chain A's surplus forward step
+//   rows jm+3 .. D+3       chain B's steps: step (se-s)+(te-t) [te-t], lane (se-s) mod LANES; the cut cells appear in both
+// so a cell at chain A's (step j, lane l) is chain B's (step D-j, lane (S_n-1-l) mod LANES).  With the pads both chains
+// run the same number of steps and no step needs a predicate.
+// LDS: lo[T+1] | cutSA cutSB [32 ints] | O2[ncap] (float2: OX, OY) | G[ncap] | cutA cutB occ [48]
+constexpr int kBandAhead = 4;   // steps per operand fetch group
+template <int LANES>
+__host__ __device__ inline size_t band_lds_bytes(int T, int S) {
+  const size_t ncap = ((size_t)S + T + 5 + 2 * kBandAhead) * LANES;
+  return sizeof(int) * ((size_t)(T + 1) + 32) + sizeof(float) * (3 * ncap + 48) + 64;
+}
+
+template <bool MOD, int LANES>
+__global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
+    const float* __restrict__ pxb, const float* __restrict__ pyb, const int32_t* __restrict__ ranges,
+    const int32_t* __restrict__ boundary, float* __restrict__ ans, float* __restrict__ gxb, float* __restrict__ gyb,
+    int B, int T, int S, int r, unsigned rinv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  const size_t cells_g = (size_t)T * r;
+  float* gx_g = gxb + (size_t)b * cells_g;
+  float* gy_g = gyb + (size_t)b * cells_g;
+  if (Sn <= 0 || Tn <= 0 || Tn == 1) {
+    // empty rectangle: ans = 0 (mi_wave_bidir.hip); a single column has no frame inside the rectangle: only the
+    // one-cell lattice has a path (no transitions at all)
+    for (size_t i = tid; i < cells_g; i += kBandThreads) { gx_g[i] = 0.0f; gy_g[i] = 0.0f; }
+    if (tid == 0) ans[b] = (Sn <= 0 || Tn <= 0) ? 0.0f : ((Sn == 1) ? 0.0f : -INFINITY);
+    return;
+  }
+  const int te = bd.te, tb = bd.tb, sb = bd.sb, se = bd.se;
+  const int D = (MOD ? 0 : (Sn - 1)) + (Tn - 1);
+  const int jm = D >> 1;                                            // the cut, in chain A's steps; chain B meets it at D - jm
+  const int rowA = 1, rowB = jm + 3;
+  const int nrow = D + 4;
+  // ---- LDS carve-up
+  int* lo = reinterpret_cast<int*>(smem);
+  int* cutSA = lo + (T + 1); int* cutSB = cutSA + 16;               // lattice row of each lane's cut cell (-1: none)
+  const int ncap = (S + T + 5 + 2 * kBandAhead) * LANES;            // > nrow rows: operand fetches run a group ahead
+  float2* O2 = reinterpret_cast<float2*>(reinterpret_cast<uintptr_t>(cutSB + 16 + 1) & ~(uintptr_t)7);
+  float* G = reinterpret_cast<float*>(O2 + ncap);
+  float* cutA = G + ncap; float* cutB = cutA + 16; float* occ = cutB + 16;   // 16 each, indexed by s & 15
+  auto div_r = [&](int i) { return (int)__umulhi((unsigned)i, rinv); };   // i / r for 0 <= i < 2^32 / r
+
+  // ---- band start per lattice column: the column t_end has no frame of its own, it continues the last frame's band
+  const int32_t* rg = ranges + (size_t)b * T * r;
+  for (int t0 = 0; t0 <= T; t0 += 4 * kBandThreads) {               // four independent loads in flight per lane
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int t = t0 + u * kBandThreads + tid; v[u] = (t <= T) ? rg[(size_t)min(t, te - 1) * r] : 0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int t = t0 + u * kBandThreads + tid; if (t <= T) lo[t] = v[u]; }
+  }
+  for (int i = tid; i < ncap; i += kBandThreads) O2[i] = make_float2(kNeg, kNeg);   // slots without a cell
+  if (tid < 32) cutSA[tid] = -1;
+  __syncthreads();
+  if (tid < LANES) { O2[(jm + 2) * LANES + tid] = make_float2(kNeg, 0.0f); }
+  auto in_band = [&](int s, int t) { const int l = lo[t]; return s >= l && s <= l + r - 1; };
+  // wavefront slot of a lattice cell in chain A's part / chain B's part of the arrays
+  auto slotA = [&](int s, int t) { return (rowA + (MOD ? (t - tb) : (s - sb) + (t - tb))) * LANES + ((s - sb) & (LANES - 1)); };
+  auto slotB = [&](int s, int t) { return (rowB + (MOD ? (te - t) : (se - s) + (te - t))) * LANES + ((se - s) & (LANES - 1)); };
+
+  // ---- operands, one input array at a time: the band is staged band shaped in the G region (16-byte loads, eight in
+  // flight per lane) and scattered from there into wavefront order with all the masking applied:
+  //   chain A's slot of a cell: OX = px(s-1, t [t-1 if modified]), OY = py(s, t-1)      (the transitions INTO the cell)
+  //   chain B's slot:           OX = px(s,t), OY = py(s,t)                              (the transitions OUT of it)
+  const int nfr = (te - tb) * r;                                     // frames [tb, te)
+  auto stage = [&](const float* src) {
+    const float* g0 = src + ((size_t)b * T + tb) * r;
+    for (int i0 = 0; i0 < nfr; i0 += 8 * 4 * kBandThreads) {
+      f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 4 * (u * kBandThreads + tid);
+        if (i + 3 < nfr) v[u] = *reinterpret_cast<const f4u*>(g0 + i);
+        else { v[u] = f4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (i + e < nfr) v[u][e] = g0[i + e]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 4 * (u * kBandThreads + tid);
+        for (int e = 0; e < 4; ++e) if (i + e < nfr) G[i + e] = v[u][e] * kLog2e;
+      }
+    }
+  };
+  auto staged = [&](int s, int t) { return G[(t - tb) * r + (s - lo[t])]; };   // band value at lattice cell (s,t), frame t < te
+  unsigned nan_acc = 0;
+  auto operands = [&](auto xtag) {
+    constexpr bool ISX = decltype(xtag)::value;
+    float* O = reinterpret_cast<float*>(O2) + (ISX ? 0 : 1);
+    for (int i = tid; i < Tn * r; i += kBandThreads) {
+      const int q = div_r(i);
+      const int t = tb + q, k = i - q * r;
+      const int s = lo[t] + k;
+      if (s < sb || s > se) continue;
+      const int dg = MOD ? (t - tb) : (s - sb) + (t - tb);
+      if (dg <= jm) {
+        float av = kNeg;
+        if (ISX) { const int tx = MOD ? t - 1 : t; if (s - 1 >= sb && tx >= tb && tx <= te - 1 && in_band(s - 1, tx)) av = staged(s - 1, tx); }
+        else { if (t - 1 >= tb && in_band(s, t - 1)) av = staged(s, t - 1); if (s == sb && t == tb) av = 0.0f; }   // origin trick
+        nan_acc = max(nan_acc, __float_as_uint(av) & 0x7fffffffu);
+        O[2 * slotA(s, t)] = fmaxf(av, kNeg);
+        if (ISX && dg == jm) cutSA[(s - sb) & (LANES - 1)] = s;
+      }
+      if (dg >= jm) {
+        float bv = kNeg;
+        if (t <= te - 1) {
+          if (ISX) { const int tnx = MOD ? t + 1 : t; if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) bv = staged(s, t); }
+          else if (in_band(s, t + 1)) bv = staged(s, t);
+        }
+        if (!ISX && s == se && t == te) bv = 0.0f;                   // chain B's origin is the end cell
+        nan_acc = max(nan_acc, __float_as_uint(bv) & 0x7fffffffu);
+        O[2 * slotB(s, t)] = fmaxf(bv, kNeg);
+        if (ISX && dg == jm) cutSB[(se - s) & (LANES - 1)] = s;
+      }
+    }
+  };
+  stage(pxb);
+  __syncthreads();
+  operands(std::true_type{});
+  __syncthreads();
+  stage(pyb);
+  __syncthreads();
+  operands(std::false_type{});
+  const bool poisoned = __syncthreads_or(nan_acc > 0x7f800000u) != 0;
+
+  // ---- the two chains, in wave 0: chain A in DPP rows 0 and 2, chain B in DPP rows 1 and 3, and with LANES = 8 both
+  // halves of a DPP row carry the same 8-lane chain, which makes the 16-lane rotate an 8-lane one.  All the copies compute
+  // and store the same values to the same addresses, so no step carries a predicate.  The other waves wait at the barrier
+  // behind this block; inside it there is a single wave, whose LDS operations execute in program order ("write, then
+  // read by other lanes" needs a compiler fence only).
+  if (wave == 0) {
+    constexpr int U = kBandAhead;
+    const int l16 = lane & 15;
+    const int lg = l16 & (LANES - 1);
+    const bool isB = ((lane >> 4) & 1) == 1;
+    if (lane < LANES) G[lane] = 0.0f;                         // the front pad row (the staging area covered it)
+    float val = (lg == 0) ? 0.0f : kNeg;                      // origin trick: the first cell starts from 0 with OY = 0
+    // ---- phase 1: forward, both chains D - jm + 1 steps (chain A's last one may be the pad step).  Operands are fetched
+    // a group of U steps ahead of their use, at immediate offsets from one running address.
+    const int n1 = D - jm + 1;
+    const int base1 = (isB ? rowB : rowA) * LANES + lg;
+    auto fwd = [&](int slot, float2 o) {
+      const float up = dpp_row_ror1(val);
+      const float a_ = up + o.x, b_ = val + o.y;
+      const float d = a_ - b_;
+      const float ex = __builtin_amdgcn_exp2f(-__builtin_fabsf(d));
+      val = fmaxf(a_, b_) + __builtin_amdgcn_logf(1.0f + ex);
+      const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+      G[slot] = (d >= 0.0f) ? rc : ex * rc;
+    };
+    {
+      float2 cur[U], nxt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = O2[base1 + u * LANES];
+      int i = 0;
+      for (; i + U <= n1; i += U) {
+        const int sl = base1 + i * LANES;
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = O2[sl + (U + u) * LANES];
+#pragma unroll
+        for (int u = 0; u < U; ++u) fwd(sl + u * LANES, cur[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      }
+      for (; i < n1; ++i) fwd(base1 + i * LANES, O2[base1 + i * LANES]);
+    }
+    // ---- the cut: p + q per cut cell (keyed by s mod 16: at most one cut cell per residue), ans, occupancies
+    if (lane < 48) cutA[lane] = kNeg;                         // cutA, cutB, occ
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int scut = (isB ? cutSB : cutSA)[lg];               // lattice row of this lane's cut cell
+    if (scut >= 0) (isB ? cutB : cutA)[scut & 15] = val;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const float v = cutA[l16] + cutB[l16];
+      const float m = row16_max(v);
+      const float e = exp2f(v - m);
+      const float sum = row16_sum(e);
+      const float total = m + log2f(sum);
+      const bool dead = !(total > kNegThresh);
+      if (lane < 16) occ[lane] = (dead || poisoned) ? 0.0f : e / sum;
+      if (lane == 0) ans[b] = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : total * kLn2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float inj = (scut >= 0) ? occ[scut & 15] : 0.0f;   // the occupancy this lane injects at its cut cell
+    // ---- phase 2: flow.  Each chain walks on from the cut through the other chain's half: at its step j it is on the
+    // cells the other chain had at step D - j (chain B's surplus step lands on the front pad row).  No masks: a transition
+    // that does not exist carries exactly zero flow (its source's ratio is exactly 0 or 1, or its source got no flow), and
+    // slots without a cell receive none.  Chain A leaves in each cell's CHAIN-B slot what entered the cell through its two
+    // incoming transitions; chain B leaves in each cell's CHAIN-A slot what it passed towards the origin through the
+    // cell's two outgoing transitions (the cut cells' own slots get values nobody reads).
+    float xo = 0.0f, yo = 0.0f;
+    const int n2 = D - jm + 1;
+    const int top = (isB ? rowA + jm : rowB + D - jm) * LANES + ((Sn - 1 - lg) & (LANES - 1));
+    auto flow = [&](int slot, float g, float add) {
+      const float xin = dpp_row_ror1(xo), yin = yo;
+      const float pg = xin + yin + add;
+      O2[slot] = make_float2(xin, yin);
+      xo = pg * g; yo = pg - xo;
+    };
+    flow(top, G[top], inj);
+    {
+      int i = 1;
+      for (; i + U <= n2; i += U) {
+        const int sl = top - (i + U - 1) * LANES;              // the group's lowest slot
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) g[u] = G[sl + (U - 1 - u) * LANES];
+#pragma unroll
+        for (int u = 0; u < U; ++u) flow(sl + (U - 1 - u) * LANES, g[u], 0.0f);
+      }
+      for (; i < n2; ++i) flow(top - i * LANES, G[top - i * LANES], 0.0f);
+    }
+  }   // wave 0
+  __syncthreads();
+  // ---- store the occupancies band shaped: gx_band[b,t,k] = px_grad[b, s0+k, t], gy_band likewise; zero elsewhere.
+  // A transition whose source cell lies in front of the cut was handled by chain B (flow kept at the source cell), one
+  // whose source lies on or behind the cut by chain A (flow kept at the destination cell).
+  for (int i = tid; i < T * r; i += kBandThreads) {
+    const int t = div_r(i), k = i - t * r;
+    float fx = 0.0f, fy = 0.0f;
+    if (t >= tb && t < te) {
+      const int s = lo[t] + k;
+      if (s >= sb && s <= se) {
+        const int dg = MOD ? (t - tb) : (s - sb) + (t - tb);
+        if (dg < jm) { const float2 f = O2[slotA(s, t)]; fx = f.x; fy = f.y; }
+        else {
+          const int tnx = MOD ? t + 1 : t;
+          if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) fx = O2[slotB(s + 1, tnx)].x;
+          if (in_band(s, t + 1)) fy = O2[slotB(s, t + 1)].y;
+        }
+      }
+    }
+    gx_g[i] = fx;
+    gy_g[i] = fy;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- gradient w.r.t. logits
+// the band_grad_kernel of pruned_logprobs.hip with the occupancies read band shaped (row = (b,t,k)); one wave per row.
+template <bool VEC>
+__global__ void band_grad_banded_kernel(const float* __restrict__ logits, const int32_t* __restrict__ symbols,
+                                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ boundary,
+                                        const float* __restrict__ lse, const float* __restrict__ gxb,
+                                        const float* __restrict__ gyb, const Scale scale, int blank, int modified,
+                                        float* __restrict__ glogits, size_t rows, int T, int S, int C, int r) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t bt = row / r;
+  const int k = (int)(row - bt * r);
+  const int b = (int)(bt / T);
+  const int t = (int)(bt - (size_t)b * T);
+  const int s = ranges[bt * r] + k;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const float sc = scale.at(b);
+  float gx = 0.0f;
+  int sym = blank;
+  const bool sok = s >= 0 && s <= S;
+  if (sok && s < S) {
+    sym = symbols[(size_t)b * S + s];
+    if (modified || t != te) gx = gxb[row] * sc;
+  }
+  const float gy = sok ? gyb[row] * sc : 0.0f;
+  const float tot = gx + gy;
+  const float l = lse[row];
+  const float* x = logits + row * C;
+  float* g = glogits + row * C;
+  if (VEC) {
+    const f4u* x4 = reinterpret_cast<const f4u*>(x);
+    f4u* g4 = reinterpret_cast<f4u*>(g);
+    const int n4 = C >> 2;
+    for (int i = lane; i < n4; i += 64) {
+      const f4 v = x4[i];
+      f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = 4 * i + e;
+        float val = -tot * __expf(v[e] - l);
+        if (cc == sym) val += gx;
+        if (cc == blank) val += gy;
+        o[e] = val;
+      }
+      g4[i] = o;
+    }
+  } else {
+    for (int cc = lane; cc < C; cc += 64) {
+      float val = -tot * __expf(x[cc] - l);
+      if (cc == sym) val += gx;
+      if (cc == blank) val += gy;
+      g[cc] = val;
+    }
+  }
+}
+
+}  // namespace
+
+// 8-lane chains while the band is at most 8 rows wide (half the LDS), 16-lane chains up to 16 rows
+static int band_lanes(int T, int S, int r) {
+  if (r < 1 || T < 1 || S < 0) return 0;
+  if (r <= 8 && band_lds_bytes<8>(T, S) <= (size_t)150 * 1024) return 8;
+  if (r <= 16 && band_lds_bytes<16>(T, S) <= (size_t)150 * 1024) return 16;
+  return 0;
+}
+int mi_band_supported(int T, int S, int r) { return band_lanes(T, S, r) != 0 ? 1 : 0; }
+
+int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
+                const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C,
+                int r, int modified, hipStream_t st) {
+  const size_t rows = (size_t)B * T * r;
+  if (rows == 0) return FTR_OK;
+  const unsigned blocks = (unsigned)((rows + 255) / 256);
+  if (modified) hipLaunchKernelGGL(band_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, logits, symbols, ranges, boundary, lse, blank, delay_penalty, pxb, pyb, rows, T, S, C, r);
+  else hipLaunchKernelGGL(band_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, logits, symbols, ranges, boundary, lse, blank, delay_penalty, pxb, pyb, rows, T, S, C, r);
+  return check_launch("band_gather");
+}
+
+int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ans,
+            float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st) {
+  const int lanes = band_lanes(T, S, r);
+  if (!lanes) { set_error("mutual_information_band: T=%d S=%d r=%d does not fit the LDS-resident kernel", T, S, r); return FTR_ERR_UNSUPPORTED; }
+  if ((uint64_t)(T + 1) * r * r >= (1ull << 32)) { set_error("mutual_information_band: T * r too large"); return FTR_ERR_UNSUPPORTED; }
+  const unsigned rinv = (unsigned)(((1ull << 32) + r - 1) / r);   // i / r == umulhi(i, rinv) while i * (r - 1) < 2^32
+  static bool big_ok = false;
+  if (!big_ok) {   // 156 KB: the kernel also has a few bytes of static LDS (__syncthreads_or)
+    const void* ks[4] = {reinterpret_cast<const void*>(mi_band_kernel<true, 8>), reinterpret_cast<const void*>(mi_band_kernel<false, 8>),
+                         reinterpret_cast<const void*>(mi_band_kernel<true, 16>), reinterpret_cast<const void*>(mi_band_kernel<false, 16>)};
+    for (const void* k : ks)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
+        (void)hipGetLastError(); set_error("mutual_information_band: cannot raise the dynamic LDS limit"); return FTR_ERR_LAUNCH;
+      }
+    big_ok = true;
+  }
+#define FTR_BAND_LAUNCH(MODV, LV) hipLaunchKernelGGL((mi_band_kernel<MODV, LV>), dim3(B), dim3(kBandThreads), band_lds_bytes<LV>(T, S), st, \
+    pxb, pyb, ranges, boundary, ans, gxb, gyb, B, T, S, r, rinv)
+  if (lanes == 8) { if (modified) FTR_BAND_LAUNCH(true, 8); else FTR_BAND_LAUNCH(false, 8); }
+  else { if (modified) FTR_BAND_LAUNCH(true, 16); else FTR_BAND_LAUNCH(false, 16); }
+#undef FTR_BAND_LAUNCH
+  return check_launch("mi_band");
+}
+
+int band_grad_banded(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
+                     int blank, const float* lse, const float* gxb, const float* gyb, Scale scale, float* glogits, int B,
+                     int T, int S, int C, int r, int modified, hipStream_t st) {
+  const size_t rows = (size_t)B * T * r;
+  if (rows == 0) return FTR_OK;
+  const int wpb = 4;
+  const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
+  if ((C & 3) == 0) hipLaunchKernelGGL(band_grad_banded_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, logits, symbols, ranges, boundary, lse, gxb, gyb, scale, blank, modified, glogits, rows, T, S, C, r);
+  else hipLaunchKernelGGL(band_grad_banded_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, logits, symbols, ranges, boundary, lse, gxb, gyb, scale, blank, modified, glogits, rows, T, S, C, r);
+  return check_launch("band_grad_banded");
+}
+
+}  // namespace ftr

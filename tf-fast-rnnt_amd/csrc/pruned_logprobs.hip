@@ -224,10 +224,8 @@ int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream
   return check_launch("negated_reduce");
 }
 
-int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges,
-                        const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px,
-                        float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st) {
-  const size_t rows = (size_t)B * T * r;
+// logsumexp over the last axis of [rows, C] (rnnt_loss.py:942): picks the register-resident kernel where it fits
+int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st) {
   if (rows == 0) return FTR_OK;
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
@@ -239,7 +237,15 @@ int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32
   else if ((C & 3) == 0 && C <= 1024) hipLaunchKernelGGL((lse_rows_reg_kernel<4, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else if ((C & 3) == 0) hipLaunchKernelGGL(lse_rows_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else hipLaunchKernelGGL(lse_rows_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
-  int rc = check_launch("lse_rows");
+  return check_launch("lse_rows");
+}
+
+int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges,
+                        const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px,
+                        float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st) {
+  const size_t rows = (size_t)B * T * r;
+  if (rows == 0) return FTR_OK;
+  int rc = lse_rows(logits, lse, rows, C, st);
   if (rc != FTR_OK) return rc;
   const int threads = 256;
   const dim3 grid((T + 1 + threads - 1) / threads, S + 1, B);

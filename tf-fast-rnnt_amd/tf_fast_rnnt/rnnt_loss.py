@@ -313,7 +313,9 @@ def rnnt_loss_simple(
 
 def _identity_ranges(B: int, T: int, S1: int, device) -> torch.Tensor:
     """ranges[b,t,:] = 0..S: with every row in range the pruned builder IS the joint builder (its band is the lattice)."""
-    return torch.arange(S1, dtype=torch.int32, device=device).expand(B, T, S1).contiguous()
+    ranges = torch.arange(S1, dtype=torch.int32, device=device).expand(B, T, S1).contiguous()
+    ranges._ftr_monotone = True
+    return ranges
 
 
 def get_rnnt_logprobs_joint(
@@ -415,6 +417,10 @@ def get_rnnt_prune_ranges(
                                                    _ptr(scratch), B, S, T, T1, s_range, ctypes.byref(r_eff),
                                                    _stream_ptr(px_grad))
     assert r_eff.value == r
+    # what the kernel guarantees (rnnt_loss.py:673-677): ranges[b,t,0] non-decreasing in t, inside [0, S - r + 1].
+    # rnnt_loss_pruned runs the recursion on the band itself for ranges that carry this mark (ftr_mutual_information_band_f32)
+    # and on full-size lattices for any other ranges tensor.
+    ranges._ftr_monotone = True
     return ranges
 
 
@@ -507,7 +513,10 @@ def _pruned_inputs(logits, symbols, ranges, boundary):
         raise TypeError("logits must be float32")
     B, T, r, C = logits.shape
     symbols = torch.as_tensor(symbols, device=logits.device).to(torch.int32).contiguous()
+    ranges_in = ranges
     ranges = torch.as_tensor(ranges, device=logits.device).to(torch.int32).contiguous()
+    if ranges is not ranges_in and getattr(ranges_in, "_ftr_monotone", False):
+        ranges._ftr_monotone = True      # a dtype / layout / device copy of marked ranges is still monotone
     if tuple(ranges.shape) != (B, T, r):
         raise ValueError(f"ranges must have shape {(B, T, r)}, got {tuple(ranges.shape)}")
     if symbols.dim() != 2 or symbols.shape[0] != B:
@@ -535,11 +544,22 @@ def get_rnnt_logprobs_pruned(
     return px, py
 
 
+def _band_path_ok(ranges, T: int, S: int, r: int) -> bool:
+    """The band-native recursion needs monotone ranges (only get_rnnt_prune_ranges' own output is known to be) and a band
+    that fits its LDS-resident kernel."""
+    return bool(getattr(ranges, "_ftr_monotone", False)) and \
+        _lib.lib().ftr_mutual_information_band_supported(int(T), int(S), int(r)) == 1
+
+
 class _PrunedLoss(torch.autograd.Function):
-    """rnnt_loss_pruned for regular/modified with the whole chain native: logsumexp + band->lattice,
-    recursion forward, recursion backward (occupancies), and in backward() one streaming kernel that
-    turns occupancies * upstream gradient into d loss / d logits (fusing _RNNTLossGrad,
-    __init__.py:154-162, into the softmax-gradient writer)."""
+    """rnnt_loss_pruned for regular/modified with the whole chain native.
+
+    Band path (ranges from get_rnnt_prune_ranges, band fits the kernel): logsumexp + band gather -> forward recursion,
+    cut and backward recursion on the band [B,T,r] in one launch (ftr_mutual_information_band_f32; no full-size lattice
+    exists) -> in backward() one streaming kernel turns the band-shaped occupancies * upstream gradient into
+    d loss / d logits.
+    Lattice path (any other ranges): logsumexp + band->lattice, recursion forward / backward on the full-size lattices
+    (what the reference does, rnnt_loss.py:968-1013), the same streaming kernel fed from the lattices."""
 
     @staticmethod
     def forward(ctx, logits, symbols, ranges, termination_symbol, boundary, modified, delay_penalty, code):
@@ -549,18 +569,37 @@ class _PrunedLoss(torch.autograd.Function):
         x = logits.detach().contiguous()
         need = logits.requires_grad
         lse = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
-        px = torch.empty((B, S, T1), dtype=torch.float32, device=x.device)
-        py = torch.empty((B, S + 1, T), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _lib.call("ftr_pruned_logprobs_fwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary),
-                                                              int(termination_symbol), float(delay_penalty), _ptr(lse),
-                                                              _ptr(px), _ptr(py), B, T, S, C, r, int(modified),
-                                                              _stream_ptr(x))
-        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
-        del px, py
-        if need:
-            ctx.save_for_backward(x, symbols, ranges, lse, px_grad, py_grad,
-                                  boundary if boundary is not None else torch.empty(0))
+        ctx.band = _band_path_ok(ranges, T, S, r)
+        if ctx.band:
+            pxb = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
+            pyb = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
+            gxb = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
+            gyb = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
+            ans = torch.empty((B,), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                st = _stream_ptr(x)
+                _lib.call("ftr_pruned_band_fwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary),
+                          int(termination_symbol), float(delay_penalty), _ptr(lse), _ptr(pxb), _ptr(pyb),
+                          B, T, S, C, r, int(modified), st)
+                _lib.call("ftr_mutual_information_band_f32", _ptr(pxb), _ptr(pyb), _ptr(ranges), _ptr(boundary), _ptr(ans),
+                          _ptr(gxb), _ptr(gyb), B, T, S, r, int(modified), st)
+            del pxb, pyb
+            if need:
+                ctx.save_for_backward(x, symbols, ranges, lse, gxb, gyb,
+                                      boundary if boundary is not None else torch.empty(0))
+        else:
+            px = torch.empty((B, S, T1), dtype=torch.float32, device=x.device)
+            py = torch.empty((B, S + 1, T), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.call("ftr_pruned_logprobs_fwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary),
+                                                                  int(termination_symbol), float(delay_penalty), _ptr(lse),
+                                                                  _ptr(px), _ptr(py), B, T, S, C, r, int(modified),
+                                                                  _stream_ptr(x))
+            ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
+            del px, py
+            if need:
+                ctx.save_for_backward(x, symbols, ranges, lse, px_grad, py_grad,
+                                      boundary if boundary is not None else torch.empty(0))
         ctx.has_boundary = boundary is not None
         ctx.meta = (int(termination_symbol), int(modified), int(code))
         return _negated_reduce_native(ans, code)
@@ -575,8 +614,9 @@ class _PrunedLoss(torch.autograd.Function):
         S = symbols.shape[1]
         g = torch.empty_like(x)
         scale, stride, mul = _upstream_scale(g_loss, code, B)
+        name = "ftr_pruned_band_bwd_scaled_f32" if ctx.band else "ftr_pruned_logprobs_bwd_scaled_f32"
         with torch.cuda.device(x.device):
-            _lib.call("ftr_pruned_logprobs_bwd_scaled_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary), blank,
+            _lib.call(name, _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary), blank,
                       _ptr(lse), _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul, _ptr(g),
                       B, T, S, C, r, modified, _stream_ptr(x))
         return g, None, None, None, None, None, None, None
