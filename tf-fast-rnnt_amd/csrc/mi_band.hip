@@ -85,18 +85,26 @@ __global__ void band_gather_kernel(const float* __restrict__ logits, const int32
 
 // ---------------------------------------------------------------------------------------- the band recursion
 // Wavefront-ordered arrays, [row][lane], LANES lanes per row:
-//   row 0                  pad (G = 0): where the shorter flow walk takes its one surplus step
-//   rows 1 .. jm+1         chain A's steps: cell (s,t) at step (s-sb)+(t-tb) [modified: t-tb], lane (s-sb) mod LANES
-//   row jm+2               pad (OX = -inf, OY = 0: a step that leaves the value unchanged), chain A's surplus forward step
-//   rows jm+3 .. D+3       chain B's steps: step (se-s)+(te-t) [te-t], lane (se-s) mod LANES; the cut cells appear in both
+//   rows 0 .. 2U-1         only ever fetched ahead, never used
+//   row 2U                 pad (G = 0): where the shorter flow walk takes its one surplus step
+//   + 1 .. jm+1            chain A's steps: cell (s,t) at step (s-sb)+(t-tb) [modified: t-tb], lane (s-sb) mod LANES
+//   + jm+2                 pad (OX = -inf, OY = 0: a step that leaves the value unchanged), chain A's surplus forward step
+//   + jm+3 .. D+3          chain B's steps: step (se-s)+(te-t) [te-t], lane (se-s) mod LANES; the cut cells appear in both
+//   2U more rows           only ever fetched ahead
 // so a cell at chain A's (step j, lane l) is chain B's (step D-j, lane (S_n-1-l) mod LANES).  With the pads both chains
 // run the same number of steps and no step needs a predicate.
 // LDS: lo[T+1] | cutSA cutSB [32 ints] | O2[ncap] (float2: OX, OY) | G[ncap] | cutA cutB occ [48]
+#ifdef FTR_BAND_STAMPS   // diagnostic build: phase times of utterance 0 (s_memrealtime, 100 MHz), read by ftr_debug_band_stamps()
+static __device__ unsigned long long g_bstamp[16];
+#define FTR_BSTAMP(k) do { if (b == 0 && tid == 0) g_bstamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FTR_BSTAMP(k) do {} while (0)
+#endif
 constexpr int kBandAhead = 4;   // steps per operand fetch group
 template <int LANES>
 __host__ __device__ inline size_t band_lds_bytes(int T, int S) {
-  const size_t ncap = ((size_t)S + T + 5 + 2 * kBandAhead) * LANES;
-  return sizeof(int) * ((size_t)(T + 1) + 32) + sizeof(float) * (3 * ncap + 48) + 64;
+  const size_t ncap = ((size_t)S + T + 5 + 4 * kBandAhead) * LANES;
+  return sizeof(int) * ((size_t)(T + 2) + 32) + sizeof(float) * (3 * ncap + 48) + 64;
 }
 
 template <bool MOD, int LANES>
@@ -121,16 +129,16 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     if (tid == 0) ans[b] = (Sn <= 0 || Tn <= 0) ? 0.0f : ((Sn == 1) ? 0.0f : -INFINITY);
     return;
   }
+  FTR_BSTAMP(0);
   const int te = bd.te, tb = bd.tb, sb = bd.sb, se = bd.se;
   const int D = (MOD ? 0 : (Sn - 1)) + (Tn - 1);
   const int jm = D >> 1;                                            // the cut, in chain A's steps; chain B meets it at D - jm
-  const int rowA = 1, rowB = jm + 3;
-  const int nrow = D + 4;
+  const int rowA = 1 + 2 * kBandAhead, rowB = rowA + jm + 2;
   // ---- LDS carve-up
   int* lo = reinterpret_cast<int*>(smem);
-  int* cutSA = lo + (T + 1); int* cutSB = cutSA + 16;               // lattice row of each lane's cut cell (-1: none)
-  const int ncap = (S + T + 5 + 2 * kBandAhead) * LANES;            // > nrow rows: operand fetches run a group ahead
-  float2* O2 = reinterpret_cast<float2*>(reinterpret_cast<uintptr_t>(cutSB + 16 + 1) & ~(uintptr_t)7);
+  int* cutSA = lo + ((T + 2) & ~1); int* cutSB = cutSA + 16;        // lattice row of each lane's cut cell (-1: none)
+  const int ncap = (S + T + 5 + 4 * kBandAhead) * LANES;            // fetches run up to two groups past either end
+  float2* O2 = reinterpret_cast<float2*>(cutSB + 16);               // 8-byte aligned: an even number of ints in front
   float* G = reinterpret_cast<float*>(O2 + ncap);
   float* cutA = G + ncap; float* cutB = cutA + 16; float* occ = cutB + 16;   // 16 each, indexed by s & 15
   auto div_r = [&](int i) { return (int)__umulhi((unsigned)i, rinv); };   // i / r for 0 <= i < 2^32 / r
@@ -147,7 +155,8 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
   for (int i = tid; i < ncap; i += kBandThreads) O2[i] = make_float2(kNeg, kNeg);   // slots without a cell
   if (tid < 32) cutSA[tid] = -1;
   __syncthreads();
-  if (tid < LANES) { O2[(jm + 2) * LANES + tid] = make_float2(kNeg, 0.0f); }
+  FTR_BSTAMP(1);
+  if (tid < LANES) O2[(rowA + jm + 1) * LANES + tid] = make_float2(kNeg, 0.0f);   // chain A's pad step
   auto in_band = [&](int s, int t) { const int l = lo[t]; return s >= l && s <= l + r - 1; };
   // wavefront slot of a lattice cell in chain A's part / chain B's part of the arrays
   auto slotA = [&](int s, int t) { return (rowA + (MOD ? (t - tb) : (s - sb) + (t - tb))) * LANES + ((s - sb) & (LANES - 1)); };
@@ -209,12 +218,16 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
   };
   stage(pxb);
   __syncthreads();
+  FTR_BSTAMP(2);
   operands(std::true_type{});
   __syncthreads();
+  FTR_BSTAMP(3);
   stage(pyb);
   __syncthreads();
+  FTR_BSTAMP(4);
   operands(std::false_type{});
   const bool poisoned = __syncthreads_or(nan_acc > 0x7f800000u) != 0;
+  FTR_BSTAMP(5);
 
   // ---- the two chains, in wave 0: chain A in DPP rows 0 and 2, chain B in DPP rows 1 and 3, and with LANES = 8 both
   // halves of a DPP row carry the same 8-lane chain, which makes the 16-lane rotate an 8-lane one.  All the copies compute
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     const int l16 = lane & 15;
     const int lg = l16 & (LANES - 1);
     const bool isB = ((lane >> 4) & 1) == 1;
-    if (lane < LANES) G[lane] = 0.0f;                         // the front pad row (the staging area covered it)
+    if (lane < LANES) G[(rowA - 1) * LANES + lane] = 0.0f;    // the front pad row (the staging area covered it)
     float val = (lg == 0) ? 0.0f : kNeg;                      // origin trick: the first cell starts from 0 with OY = 0
     // ---- phase 1: forward, both chains D - jm + 1 steps (chain A's last one may be the pad step).  Operands are fetched
     // a group of U steps ahead of their use, at immediate offsets from one running address.
@@ -242,21 +255,25 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       G[slot] = (d >= 0.0f) ? rc : ex * rc;
     };
     {
-      float2 cur[U], nxt[U];
+      // two register sets, each filled half an iteration (U steps) before it is used
+      float2 oa[U], ob[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) cur[u] = O2[base1 + u * LANES];
+      for (int u = 0; u < U; ++u) oa[u] = O2[base1 + u * LANES];
       int i = 0;
-      for (; i + U <= n1; i += U) {
+      for (; i + 2 * U <= n1; i += 2 * U) {
         const int sl = base1 + i * LANES;
 #pragma unroll
-        for (int u = 0; u < U; ++u) nxt[u] = O2[sl + (U + u) * LANES];
+        for (int u = 0; u < U; ++u) ob[u] = O2[sl + (U + u) * LANES];
 #pragma unroll
-        for (int u = 0; u < U; ++u) fwd(sl + u * LANES, cur[u]);
+        for (int u = 0; u < U; ++u) fwd(sl + u * LANES, oa[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < U; ++u) oa[u] = O2[sl + (2 * U + u) * LANES];
+#pragma unroll
+        for (int u = 0; u < U; ++u) fwd(sl + (U + u) * LANES, ob[u]);
       }
       for (; i < n1; ++i) fwd(base1 + i * LANES, O2[base1 + i * LANES]);
     }
+    FTR_BSTAMP(6);
     // ---- the cut: p + q per cut cell (keyed by s mod 16: at most one cut cell per residue), ans, occupancies
     if (lane < 48) cutA[lane] = kNeg;                         // cutA, cutB, occ
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -275,6 +292,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const float inj = (scut >= 0) ? occ[scut & 15] : 0.0f;   // the occupancy this lane injects at its cut cell
+    FTR_BSTAMP(7);
     // ---- phase 2: flow.  Each chain walks on from the cut through the other chain's half: at its step j it is on the
     // cells the other chain had at step D - j (chain B's surplus step lands on the front pad row).  No masks: a transition
     // that does not exist carries exactly zero flow (its source's ratio is exactly 0 or 1, or its source got no flow), and
@@ -284,25 +302,35 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     float xo = 0.0f, yo = 0.0f;
     const int n2 = D - jm + 1;
     const int top = (isB ? rowA + jm : rowB + D - jm) * LANES + ((Sn - 1 - lg) & (LANES - 1));
-    auto flow = [&](int slot, float g, float add) {
+    auto flow = [&](int slot, float g, auto first) {
       const float xin = dpp_row_ror1(xo), yin = yo;
-      const float pg = xin + yin + add;
+      float pg = xin + yin;
+      if (decltype(first)::value) pg += inj;
       O2[slot] = make_float2(xin, yin);
       xo = pg * g; yo = pg - xo;
     };
-    flow(top, G[top], inj);
+    flow(top, G[top], std::true_type{});
     {
+      // step i reads slot top - i * LANES, going down in memory: the 2 U rows in front of the pad row take the fetches
+      // that run past the end
+      float ga[U], gb[U];
+      auto gslot = [&](int i) { return top - i * LANES; };
+#pragma unroll
+      for (int u = 0; u < U; ++u) ga[u] = G[gslot(1 + u)];
       int i = 1;
-      for (; i + U <= n2; i += U) {
-        const int sl = top - (i + U - 1) * LANES;              // the group's lowest slot
-        float g[U];
+      for (; i + 2 * U <= n2; i += 2 * U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) g[u] = G[sl + (U - 1 - u) * LANES];
+        for (int u = 0; u < U; ++u) gb[u] = G[gslot(i + U + u)];
 #pragma unroll
-        for (int u = 0; u < U; ++u) flow(sl + (U - 1 - u) * LANES, g[u], 0.0f);
+        for (int u = 0; u < U; ++u) flow(top - (i + u) * LANES, ga[u], std::false_type{});
+#pragma unroll
+        for (int u = 0; u < U; ++u) ga[u] = G[gslot(i + 2 * U + u)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) flow(top - (i + U + u) * LANES, gb[u], std::false_type{});
       }
-      for (; i < n2; ++i) flow(top - i * LANES, G[top - i * LANES], 0.0f);
+      for (; i < n2; ++i) flow(top - i * LANES, G[top - i * LANES], std::false_type{});
     }
+    FTR_BSTAMP(8);
   }   // wave 0
   __syncthreads();
   // ---- store the occupancies band shaped: gx_band[b,t,k] = px_grad[b, s0+k, t], gy_band likewise; zero elsewhere.
@@ -326,6 +354,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     gx_g[i] = fx;
     gy_g[i] = fy;
   }
+  FTR_BSTAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------- gradient w.r.t. logits
@@ -430,6 +459,12 @@ int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int
 #undef FTR_BAND_LAUNCH
   return check_launch("mi_band");
 }
+
+#ifdef FTR_BAND_STAMPS
+extern "C" int ftr_debug_band_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamp), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int band_grad_banded(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
                      int blank, const float* lse, const float* gxb, const float* gyb, Scale scale, float* glogits, int B,
