@@ -365,6 +365,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave rocBLAS' default kernel choice for the three normaliser GEMMs (tf_fast_rnnt.tune_normalizer_gemms)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-call HIP events on every n-th timed step (1 = every step)")
     ap.add_argument("--first-pass", default=None, choices=["simple", "smoothed"],
@@ -414,6 +416,13 @@ def main():
         torch.cuda.synchronize()
 
     ft._lib.set_profile_hook(timer)
+    if not args.no_gemm_tuning:
+        # one-off library-GEMM kernel selection for this process (package feature); the selection happens in this extra
+        # untimed step, in front of the W warm-up steps
+        import tempfile
+        ft.tune_normalizer_gemms(True, os.path.join(tempfile.gettempdir(), f"ftr_bench_gemm_choices_{os.getpid()}.csv"))
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.reset_peak_memory_stats(dev)
@@ -506,6 +515,7 @@ def main():
                              "frac_of_peak": round(tot_alg / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tot_us > 0 else None},
         "kernels": kernels,
         "loss": float(last.item()),
+        "gemm_tuning": not args.no_gemm_tuning,
     }
     if world == 1 and not args.no_graph:
         gr = graph_replay(lambda: pruned_step(inp, r, first_pass=first_pass), args.steps)

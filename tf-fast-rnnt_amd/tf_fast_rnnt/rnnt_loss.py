@@ -33,6 +33,20 @@ _NEG_INF = float("-inf")
 _TINY = 1.401298464324817e-45
 
 
+def tune_normalizer_gemms(enable: bool = True, filename: Optional[str] = None) -> None:
+    """The three dense contractions of the simple / smoothed builders (normalisers = lm_probs @ am_probs^T and its two
+    transposes in the backward, rnnt_loss.py:180-182) are library f32 GEMMs.  rocBLAS' default kernel choice for these
+    shapes runs at 62-77 TFLOP/s on MI355X; letting the library time its candidate kernels once per shape (PyTorch's
+    TunableOp over rocBLAS / hipBLASLt) gives ~100 TFLOP/s (104/90/84 -> 65/62/60 us at B=32 T=1000 S=200 C=500).
+    Process-wide switch (it affects every torch GEMM of the process); the first call of each new shape is slow and
+    must not happen inside a stream capture.  `filename`: where the choices are stored / reloaded from."""
+    import torch.cuda.tunable as tunable
+    tunable.enable(bool(enable))
+    tunable.tuning_enable(bool(enable))
+    if filename is not None:
+        tunable.set_filename(filename)
+
+
 def _check_type(rnnt_type: str) -> None:
     if rnnt_type not in ("regular", "modified", "constrained"):
         raise ValueError(f"rnnt_type should be ('regular' | 'modified' | 'constrained'), given {rnnt_type}")
