@@ -136,20 +136,21 @@ class CallTimer:
 CALL_KERNELS = {
     "ftr_mutual_information_fwd_ws_f32": ["mi_bidir_fwd_kernel<false>"],
     "ftr_mutual_information_bwd_ws_f32": ["mi_bidir_flow_kernel<false>"],
-    "ftr_prune_ranges_i32": ["prune_argmax_kernel", "prune_adjust_kernel"],
+    "ftr_prune_ranges_i32": ["prune_argmax_once_kernel<5>", "prune_adjust_kernel"],
     "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
     "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_chunk_kernel<true>", "do_pruning_bwd_reduce_kernel"],
     "ftr_pruned_logprobs_fwd_f32": ["lse_rows_kernel<true>", "band_to_lattice_kernel<false>"],
     "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_gather_kernel<false>"],
-    "ftr_mutual_information_band_f32": ["mi_band_kernel<false>"],
+    "ftr_mutual_information_band_f32": ["mi_band_kernel<false, 8>"],
     "ftr_pruned_band_bwd_scaled_f32": ["band_grad_banded_kernel<true>"],
     "ftr_pruned_logprobs_bwd_f32": ["band_grad_kernel<false, true>"],
     "ftr_pruned_logprobs_bwd_scaled_f32": ["band_grad_kernel<false, true>"],
     "ftr_simple_logprobs_bwd_w_scaled_f32": ["simple_bwd_w_kernel<false>"],
-    "ftr_simple_logprobs_bwd_am_scaled_f32": ["simple_bwd_am_kernel<false>"],
+    "ftr_simple_logprobs_bwd_am_scaled_f32": ["simple_bwd_am_kernel<false, 16>"],
     "ftr_rowmax_exp_f32": ["rowmax_exp_kernel<true>"],
-    "ftr_simple_logprobs_fwd_f32": ["simple_fwd_kernel<false>"],
+    "ftr_simple_logprobs_fwd_f32": ["simple_fwd_kernel<false, 16>"],
+    "ftr_simple_logprobs_fused_fwd_f32": ["simple_fused_fwd_kernel<false, false, 13>"],
     "ftr_simple_logprobs_bwd_w_f32": ["simple_bwd_w_kernel<false>"],
     "ftr_simple_logprobs_bwd_am_f32": ["simple_bwd_am_kernel<false>"],
     "ftr_simple_logprobs_bwd_lm_f32": ["simple_bwd_lm_kernel"],
@@ -186,6 +187,10 @@ def algorithmic_bytes(B, T, S, C, r):
         "ftr_rowmax_exp_sum_f32": 4 * 2 * nlm,
         "ftr_simple_logprobs_fwd_f32": 4 * (nam + nlm + npy + npx + npy),   # read am, lm, prod; write px, py
         "ftr_smoothed_logprobs_fwd_f32": 4 * (nam + nlm + npy + npx + npy),
+        # fused builder: am_probs, lm_probs (+ the am / lm gathers) in, px, py and the product for the backward out;
+        # 2 * B * (S+1) * T * C flops on the f32 MFMA pipe (reported apart)
+        "ftr_simple_logprobs_fused_fwd_f32": 4 * (2 * nam + 2 * nlm + npx + 2 * npy),
+        "ftr_smoothed_logprobs_fused_fwd_f32": 4 * (2 * nam + 2 * nlm + npx + 2 * npy),
         "ftr_simple_logprobs_bwd_w_f32": 4 * (npx + 3 * npy),               # read gpx, gpy, prod; write W
         "ftr_simple_logprobs_bwd_w_scaled_f32": 4 * (npx + 3 * npy),
         "ftr_simple_logprobs_bwd_am_scaled_f32": 4 * (npx + npy + 3 * nam),

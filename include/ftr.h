@@ -284,6 +284,23 @@ int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const in
                                       int termination_symbol, double delay_penalty, float combined_scale,
                                       float lm_only_scale, float am_only_scale, float* px, float* py, int B, int T,
                                       int S, int C, int modified, void* stream);
+/* The builders with the normaliser contraction inside the kernel (f32 MFMA, MI355X addition): replaces the batched
+ * matmul of rnnt_loss.py:180-182 / :1270-1272 AND the epilogue above in one launch -- the [B,S+1,T] product never goes
+ * through memory unless `prod` is non-NULL (the backward's W kernel still reads it).  am_probs / lm_probs / am_max /
+ * lm_max come from ftr_rowmax_exp_f32.  Requires C % 4 == 0 (ftr_simple_logprobs_fused_supported); other sizes take the
+ * library-GEMM route above.  Same outputs as ftr_simple_logprobs_fwd_f32 / ftr_smoothed_logprobs_fwd_pen_f32 up to the
+ * summation order of the contraction. */
+int ftr_simple_logprobs_fused_supported(int C);
+int ftr_simple_logprobs_fused_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
+                                      const float* lm_probs, const float* am_max, const float* lm_max,
+                                      const int32_t* boundary, int termination_symbol, double delay_penalty, float* px,
+                                      float* py, float* prod, int B, int T, int S, int C, int modified, void* stream);
+int ftr_smoothed_logprobs_fused_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
+                                        const float* lm_probs, const float* am_max, const float* lm_max,
+                                        const float* lmonly_norm, const float* amonly_norm, const float* unigram_log,
+                                        const int32_t* boundary, int termination_symbol, double delay_penalty,
+                                        float combined_scale, float lm_only_scale, float am_only_scale, float* px,
+                                        float* py, float* prod, int B, int T, int S, int C, int modified, void* stream);
 int ftr_smoothed_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
                                            float scale_mul, const float* prod, const int32_t* boundary,
                                            float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,

@@ -447,6 +447,38 @@ int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const in
   return simple_logprobs_fwd(am, lm, symbols, prod, am_max, lm_max, boundary, termination_symbol, delay_penalty, lmonly_norm, amonly_norm, unigram_log, combined_scale, lm_only_scale, am_only_scale, px, py, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ftr_simple_logprobs_fused_supported(int C) { return simple_fused_supported(C); }
+
+int ftr_simple_logprobs_fused_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
+                                      const float* lm_probs, const float* am_max, const float* lm_max,
+                                      const int32_t* boundary, int termination_symbol, double delay_penalty, float* px,
+                                      float* py, float* prod, int B, int T, int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "simple_logprobs_fused_fwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "simple_logprobs_fused_fwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(am && lm && am_probs && lm_probs && am_max && lm_max && py && (symbols || S == 0) && (px || S == 0), "simple_logprobs_fused_fwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_fused_fwd(am, lm, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol, delay_penalty, nullptr, nullptr, nullptr, 1.0f, 0.0f, 0.0f, px, py, prod, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_fused_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
+                                        const float* lm_probs, const float* am_max, const float* lm_max,
+                                        const float* lmonly_norm, const float* amonly_norm, const float* unigram_log,
+                                        const int32_t* boundary, int termination_symbol, double delay_penalty,
+                                        float combined_scale, float lm_only_scale, float am_only_scale, float* px,
+                                        float* py, float* prod, int B, int T, int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "smoothed_logprobs_fused_fwd: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_fused_fwd: termination_symbol %d not in [0,%d)", termination_symbol, C);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(am && lm && am_probs && lm_probs && am_max && lm_max && lmonly_norm && amonly_norm && unigram_log && py && (symbols || S == 0) && (px || S == 0), "smoothed_logprobs_fused_fwd: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_fused_fwd(am, lm, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol, delay_penalty, lmonly_norm, amonly_norm, unigram_log, combined_scale, lm_only_scale, am_only_scale, px, py, prod, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ftr_smoothed_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
                                            float scale_mul, const float* prod, const int32_t* boundary,
                                            float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,

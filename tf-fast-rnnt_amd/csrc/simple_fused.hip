@@ -1,0 +1,253 @@
+// csrc/simple_fused.hip -- get_rnnt_logprobs / get_rnnt_logprobs_smoothed with the normaliser contraction INSIDE the
+// kernel (gfx950, f32 MFMA): /root/reference/tf_fast_rnnt/python/tf_fast_rnnt/rnnt_loss.py:180-221 (simple),
+// :1270-1365 (smoothed), :305-321 (delay penalty).
+//
+//   normalizers[b,s,t] = log(sum_c lm_probs[b,s,c] * am_probs[b,t,c] + tiny) + lm_max[b,s] + am_max[b,t]
+//   px[b,s,t] = am[b,t,sym(b,s)] + lm[b,s,sym(b,s)] - normalizers[b,s,t]      (-inf in column T / t_end, + penalty)
+//   py[b,s,t] = am[b,t,blank]    + lm[b,s,blank]    - normalizers[b,s,t]
+//
+// The reference runs this as a batched matmul that writes `normalizers` [B,S+1,T] to memory, followed by ~10 framework
+// ops over lattices.  Here one workgroup owns 64 frames x (16 NS) symbol rows of one utterance: the [t, s] tile of the
+// product is accumulated in registers with v_mfma_f32_16x16x4_f32 (arithmetic stays f32, operands from LDS, K staged 32
+// columns at a time, double buffered), and the epilogue turns the accumulators straight into px and py -- the product
+// itself leaves the kernel only when the caller asks for it (the backward's W still wants it).
+//
+// MFMA operand roles: A = am_probs tile (M = frames), B = lm_probs tile (N = symbol rows), so that an accumulator
+// register quad holds four CONSECUTIVE FRAMES of one symbol row: px / py / prod rows are written 16 bytes per lane.
+#include "ftr_common.h"
+
+namespace ftr {
+namespace {
+
+constexpr float kTinyF = 1.401298464324817e-45f;  // tf.math.nextafter(0., 1.)  (rnnt_loss.py:181)
+constexpr int kFT = 64;                           // frames per workgroup: 4 waves x one 16-frame MFMA block
+constexpr int kFK = 32;                           // columns of C staged per step
+constexpr int kFLD = kFK + 4;                     // LDS row stride (floats): 16-byte aligned, b128 fragment reads conflict free
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int NS>
+__host__ __device__ constexpr size_t fused_lds_bytes() { return sizeof(float) * 2 * (size_t)(kFT + 16 * NS) * kFLD; }
+
+// grid (ceil(T1 / 64), ceil((S+1) / (16 NS)), B), 256 threads.
+template <bool MOD, bool SMOOTH, int NS>
+__global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
+    const float* __restrict__ am, const float* __restrict__ lm, const int32_t* __restrict__ symbols,
+    const float* __restrict__ am_probs, const float* __restrict__ lm_probs, const float* __restrict__ am_max,
+    const float* __restrict__ lm_max, const int32_t* __restrict__ boundary, int blank, double delay_penalty,
+    const float* __restrict__ lmonly_norm, const float* __restrict__ amonly_norm, const float* __restrict__ ulog,
+    float cs, float ls, float as, float* __restrict__ px, float* __restrict__ py, float* __restrict__ prod_out, int T,
+    int S, int C) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][ROWS][kFLD]: rows 0..63 frames, then 16 NS symbol rows
+  constexpr int ROWS = kFT + 16 * NS;
+  constexpr int NU = (ROWS * 8 + 255) / 256;      // 16-byte pieces per thread and chunk
+  const int b = blockIdx.z, t0 = blockIdx.x * kFT, s0 = blockIdx.y * 16 * NS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T1 = MOD ? T : T + 1;
+  const float* amp = am_probs + (size_t)b * T * C;
+  const float* lmp = lm_probs + (size_t)b * (S + 1) * C;
+
+  // ---- staging plan: piece e = tid + 256 u is 4 columns (e & 7) of tile row (e >> 3)
+  const float* src[NU];
+  bool live[NU];
+  int dst[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int e = tid + 256 * u, row = e >> 3, c4 = e & 7;
+    live[u] = false; src[u] = amp; dst[u] = row * kFLD + 4 * c4;
+    if (row < kFT) { const int t = t0 + row; if (t < T) { live[u] = true; src[u] = amp + (size_t)t * C + 4 * c4; } }
+    else if (row < ROWS) { const int s = s0 + row - kFT; if (s <= S) { live[u] = true; src[u] = lmp + (size_t)s * C + 4 * c4; } }
+  }
+  auto gload = [&](int kc, f4 (&v)[NU]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int k = kc * kFK + 4 * ((tid + 256 * u) & 7);
+      v[u] = f4{0.f, 0.f, 0.f, 0.f};
+      if (live[u] && k < C) v[u] = *reinterpret_cast<const f4*>(src[u] + kc * kFK);   // C % 4 == 0: k < C covers k + 3
+    }
+  };
+  auto lstore = [&](int buf, const f4 (&v)[NU]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (tid + 256 * u < ROWS * 8) *reinterpret_cast<f4*>(smem + buf * ROWS * kFLD + dst[u]) = v[u];
+  };
+
+  v4f acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int nk = (C + kFK - 1) / kFK;
+  f4 v[NU];
+  gload(0, v);
+  lstore(0, v);
+  __syncthreads();
+  const int frag = (lane & 15) * kFLD + 4 * (lane >> 4);   // this lane's row and its 4 of every 16 columns
+#if defined(FTR_FUSED_EXP) && FTR_FUSED_EXP == 2   // diagnostic: no contraction
+  for (int kc = 0; kc < 0; ++kc) {
+#else
+  for (int kc = 0; kc < nk; ++kc) {
+#endif
+    if (kc + 1 < nk) gload(kc + 1, v);
+    const float* A = smem + (kc & 1) * ROWS * kFLD + 16 * wave * kFLD + frag;
+    const float* Bm = smem + (kc & 1) * ROWS * kFLD + kFT * kFLD + frag;
+    // One unit = the four MFMAs of (column group g, symbol block i): 2 NS units per chunk, taken in pairs that alternate
+    // between two accumulators; the B fragments run through a small register ring fetched kAheadU units ahead of their
+    // use (fetching a whole chunk's fragments up front makes the compiler recycle registers and wait on every reuse).
+    constexpr int NUNIT = (kFK / 16) * NS;
+    constexpr int kAheadU = 4, RING = 8;
+    f4 af[kFK / 16], ring[RING];
+#pragma unroll
+    for (int g = 0; g < kFK / 16; ++g) af[g] = *reinterpret_cast<const f4*>(A + 16 * g);
+    auto bfetch = [&](int u) { return *reinterpret_cast<const f4*>(Bm + (u % NS) * 16 * kFLD + 16 * (u / NS)); };
+#pragma unroll
+    for (int u = 0; u < kAheadU; ++u) if (u < NUNIT) ring[u % RING] = bfetch(u);
+#pragma unroll
+    for (int u = 0; u < NUNIT; u += 2) {
+      if (u + kAheadU < NUNIT) ring[(u + kAheadU) % RING] = bfetch(u + kAheadU);
+      if (u + kAheadU + 1 < NUNIT) ring[(u + kAheadU + 1) % RING] = bfetch(u + kAheadU + 1);
+      const int g0 = u / NS, i0 = u % NS;
+      const f4 b0 = ring[u % RING];
+      if (u + 1 < NUNIT) {
+        const int g1 = (u + 1) / NS, i1 = (u + 1) % NS;
+        const f4 b1 = ring[(u + 1) % RING];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[i0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g0][e], b0[e], acc[i0], 0, 0, 0);
+          acc[i1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g1][e], b1[e], acc[i1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g0][e], b0[e], acc[i0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the fetch-ahead order: the scheduler otherwise regroups the units and waits on fresh reads
+    }
+    if (kc + 1 < nk) lstore((kc + 1) & 1, v);
+    __syncthreads();
+  }
+
+#if defined(FTR_FUSED_EXP) && FTR_FUSED_EXP == 1   // diagnostic: no epilogue (accumulators summed into one store)
+  { float t = 0.f; for (int i = 0; i < NS; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; if (t == 123.456f) py[0] = t; return; }
+#endif
+  // ---- epilogue: lane (n = lane & 15, q = lane >> 4) holds, per symbol block i, frames tq .. tq+3 of row s0 + 16 i + n
+  const int n = lane & 15;
+  const int tq = t0 + 16 * wave + 4 * (lane >> 4);
+  if (tq >= T1) return;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const float* amb = am + (size_t)b * T * C;
+  const float* lmb = lm + (size_t)b * (S + 1) * C;
+  float amx[4], a_blank[4], aon[4], pen[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tq + j;
+    const bool in = t < T;
+    amx[j] = in ? am_max[(size_t)b * T + t] : 0.0f;
+    a_blank[j] = in ? amb[(size_t)t * C + blank] : 0.0f;
+    aon[j] = (SMOOTH && in) ? amonly_norm[(size_t)b * T + t] : 0.0f;
+    pen[j] = (delay_penalty > 0.0) ? (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty) : 0.0f;   // :305-321
+  }
+  const float ulog_blank = SMOOTH ? ulog[blank] : 0.0f;
+  // The epilogue's loads are issued in three independent batches (row scalars; lm at the symbol; the 4 x NS am gathers)
+  // so that they are all in flight together: taken block by block they form NS serial chains of three dependent loads.
+  int sym[NS];
+  float lm_blank[NS], lmx[NS], lon[NS], lm_sym[NS], ulog_sym[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = min(s0 + 16 * i + n, S);                     // rows past S: clamped loads, nothing stored
+    sym[i] = (s < S) ? min(max(symbols[(size_t)b * S + s], 0), C - 1) : blank;   // kept in bounds
+    lm_blank[i] = lmb[(size_t)s * C + blank];
+    lmx[i] = lm_max[(size_t)b * (S + 1) + s];
+    lon[i] = SMOOTH ? lmonly_norm[(size_t)b * (S + 1) + s] : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = min(s0 + 16 * i + n, S);
+    lm_sym[i] = lmb[(size_t)s * C + sym[i]];
+    ulog_sym[i] = SMOOTH ? ulog[sym[i]] : 0.0f;
+  }
+  float a_sym[NS][4];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_sym[i][j] = amb[(size_t)min(tq + j, T - 1) * C + sym[i]];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = s0 + 16 * i + n;
+    if (s > S) continue;
+    f4 vy, vx, vp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = tq + j;
+      const float pr = acc[i][j];
+      vp[j] = pr;
+      const float nrm = logf(pr + kTinyF) + lmx[i] + amx[j];                                                    // :180-186
+      float y = a_blank[j] + lm_blank[i] - nrm;                                                                 // :214-216
+      if (SMOOTH) y = y * cs + (lm_blank[i] - lon[i]) * ls + (a_blank[j] + ulog_blank - aon[j]) * as;           // :1333-1360
+      vy[j] = y;
+      float x = -INFINITY;                                                  // px[:, :, T] (:193-203), fix_for_boundary (:218-219)
+      if (s < S && t < T && (MOD || t != te)) {
+        x = a_sym[i][j] + lm_sym[i] - nrm;                                                                      // :187-211
+        if (SMOOTH) x = x * cs + (lm_sym[i] - lon[i]) * ls + (a_sym[i][j] + ulog_sym[i] - aon[j]) * as;         // :1323-1355
+      }
+      if (delay_penalty > 0.0) x += pen[j];
+      vx[j] = x;
+    }
+    float* yrow = py + ((size_t)b * (S + 1) + s) * T + tq;
+    if (tq + 3 < T) *reinterpret_cast<f4u*>(yrow) = vy;
+    else { for (int j = 0; j < 4; ++j) if (tq + j < T) yrow[j] = vy[j]; }
+    if (prod_out) {
+      float* prow = prod_out + ((size_t)b * (S + 1) + s) * T + tq;
+      if (tq + 3 < T) *reinterpret_cast<f4u*>(prow) = vp;
+      else { for (int j = 0; j < 4; ++j) if (tq + j < T) prow[j] = vp[j]; }
+    }
+    if (s < S) {
+      float* xrow = px + ((size_t)b * S + s) * T1 + tq;
+      if (tq + 3 < T1) *reinterpret_cast<f4u*>(xrow) = vx;
+      else { for (int j = 0; j < 4; ++j) if (tq + j < T1) xrow[j] = vx[j]; }
+    }
+  }
+}
+
+}  // namespace
+
+int simple_fused_supported(int C) { return (C % 4 == 0) ? 1 : 0; }
+
+int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
+                     const float* lm_probs, const float* am_max, const float* lm_max, const int32_t* boundary, int blank,
+                     double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog, float cs,
+                     float ls, float as, float* px, float* py, float* prod_out, int B, int T, int S, int C, int modified,
+                     hipStream_t st) {
+  if (!simple_fused_supported(C)) { set_error("simple_logprobs_fused_fwd: C = %d is not a multiple of 4", C); return FTR_ERR_UNSUPPORTED; }
+  const int T1 = modified ? T : T + 1;
+  const int blocks = (S + 1 + 15) / 16;
+  const int ny = (blocks + 12) / 13;
+  const int need = (blocks + ny - 1) / ny;                     // symbol blocks per workgroup, <= 13
+  const int ns = need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : 13;
+  const dim3 grid((T1 + kFT - 1) / kFT, (blocks + ns - 1) / ns, B);
+  if (grid.z > 65535) { set_error("simple_logprobs_fused_fwd: B = %d > 65535", B); return FTR_ERR_UNSUPPORTED; }
+  const bool smooth = lmonly_norm != nullptr;
+#define FTR_FUSED_LAUNCH(MODV, SMV, NSV)                                                                                   \
+  do {                                                                                                                     \
+    static bool raised = false;                                                                                            \
+    if (!raised && fused_lds_bytes<NSV>() > 64 * 1024) {                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(simple_fused_fwd_kernel<MODV, SMV, NSV>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes<NSV>()) != hipSuccess) {    \
+        (void)hipGetLastError(); set_error("simple_logprobs_fused_fwd: cannot raise the dynamic LDS limit"); return FTR_ERR_LAUNCH; \
+      }                                                                                                                    \
+      raised = true;                                                                                                       \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((simple_fused_fwd_kernel<MODV, SMV, NSV>), grid, dim3(256), fused_lds_bytes<NSV>(), st, am, lm,     \
+                       symbols, am_probs, lm_probs, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm,           \
+                       amonly_norm, ulog, cs, ls, as, px, py, prod_out, T, S, C);                                         \
+  } while (0)
+#define FTR_FUSED_NS(MODV, SMV)                                                                                            \
+  do {                                                                                                                     \
+    if (ns == 4) FTR_FUSED_LAUNCH(MODV, SMV, 4); else if (ns == 7) FTR_FUSED_LAUNCH(MODV, SMV, 7);                          \
+    else if (ns == 10) FTR_FUSED_LAUNCH(MODV, SMV, 10); else FTR_FUSED_LAUNCH(MODV, SMV, 13);                               \
+  } while (0)
+  if (modified) { if (smooth) FTR_FUSED_NS(true, true); else FTR_FUSED_NS(true, false); }
+  else { if (smooth) FTR_FUSED_NS(false, true); else FTR_FUSED_NS(false, false); }
+#undef FTR_FUSED_NS
+#undef FTR_FUSED_LAUNCH
+  return check_launch("simple_logprobs_fused_fwd");
+}
+
+}  // namespace ftr

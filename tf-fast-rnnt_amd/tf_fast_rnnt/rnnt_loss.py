@@ -22,6 +22,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple, Union
 
+import os
 import torch
 
 from . import _lib
@@ -65,6 +66,29 @@ def fix_for_boundary(px: torch.Tensor, boundary: Optional[torch.Tensor] = None) 
     return px.scatter(2, idx, _NEG_INF)
 
 
+def _use_fused_builder(C: int) -> bool:
+    """The f32-MFMA builder kernel (csrc/simple_fused.hip) unless the size is outside its domain (C % 4 != 0) or
+    FTR_BUILDER_GEMM=library asks for the library-GEMM route (A/B comparisons)."""
+    return os.environ.get("FTR_BUILDER_GEMM", "fused") != "library" and bool(_lib.lib().ftr_simple_logprobs_fused_supported(int(C)))
+
+
+def _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, blank, delay_penalty, px, py,
+                    B, T, S, C, modified, st):
+    """normalisers + px / py of get_rnnt_logprobs (rnnt_loss.py:180-221): one fused launch, or library GEMM + epilogue.
+    Returns the product [B,S+1,T] (the backward's W kernel reads it)."""
+    if _use_fused_builder(C):
+        prod = torch.empty((B, S + 1, T), dtype=torch.float32, device=amc.device)
+        _lib.call("ftr_simple_logprobs_fused_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(am_probs), _ptr(lm_probs),
+                  _ptr(am_max), _ptr(lm_max), _ptr(boundary), int(blank), float(delay_penalty), _ptr(px), _ptr(py),
+                  _ptr(prod), B, T, S, C, int(modified), st)
+        return prod
+    prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                             # :180-182
+    _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
+              _ptr(lm_max), _ptr(boundary), int(blank), float(delay_penalty), _ptr(px), _ptr(py),
+              B, T, S, C, int(modified), st)
+    return prod
+
+
 class _SimpleLogprobs(torch.autograd.Function):
     """get_rnnt_logprobs (+ fix_for_boundary + delay penalty) for regular/modified: native prologue and
     epilogue kernels around the normaliser GEMM (torch.bmm -> rocBLAS), hand-written backward."""
@@ -85,10 +109,8 @@ class _SimpleLogprobs(torch.autograd.Function):
             st = _stream_ptr(amc)
             _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)        # :175-178
             _lib.call("ftr_rowmax_exp_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
-            prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                         # :180-182
-            _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
-                      _ptr(lm_max), _ptr(boundary), int(termination_symbol), float(delay_penalty), _ptr(px), _ptr(py),
-                      B, T, S, C, int(modified), st)
+            prod = _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol,
+                                   delay_penalty, px, py, B, T, S, C, modified, st)
         ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0))
         ctx.has_boundary = boundary is not None
         ctx.meta = (int(termination_symbol), int(modified))
@@ -142,10 +164,8 @@ class _SimpleLoss(torch.autograd.Function):
             st = _stream_ptr(amc)
             _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)        # :175-178
             _lib.call("ftr_rowmax_exp_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
-            prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                         # :180-182
-            _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
-                      _ptr(lm_max), _ptr(boundary), int(termination_symbol), float(delay_penalty), _ptr(px), _ptr(py),
-                      B, T, S, C, int(modified), st)
+            prod = _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol,
+                                   delay_penalty, px, py, B, T, S, C, modified, st)
         # the recursion backward (occupancies) only when somebody wants them: the caller (calc_gradients) or autograd
         need = bool(want_occupancies) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
@@ -685,7 +705,9 @@ def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, l
         _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)           # :1265-1268
         _lib.call("ftr_rowmax_exp_sum_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), _ptr(lm_sum),
                   B * (S + 1), C, st)                                                                   # :1276-1278
-        prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                            # :1270-1272
+        fused = _use_fused_builder(C)
+        prod = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev) if fused else \
+            torch.bmm(lm_probs, am_probs.transpose(1, 2))                                               # :1270-1272
         inv = 1.0 / lm_sum                                                                              # [B,S+1]
         ratio_sum = torch.mv(lm_probs.reshape(-1, C).t(), inv.reshape(-1))                               # [C]
         count = float(B * (S + 1))
@@ -697,9 +719,15 @@ def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, l
         amonly = (am_dot.log().reshape(B, T) + am_max).contiguous()                                     # :1281-1286
         ulog = u.log().contiguous()                                                                     # :1287
         lmonly = (lm_sum.log() + lm_max).contiguous()                                                   # :1288-1290
-        _lib.call("ftr_smoothed_logprobs_fwd_pen_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
-                  _ptr(lm_max), _ptr(lmonly), _ptr(amonly), _ptr(ulog), _ptr(boundary), int(termination_symbol),
-                  float(delay_penalty), cs, ls, a_s, _ptr(px), _ptr(py), B, T, S, C, int(modified), st)
+        if fused:
+            _lib.call("ftr_smoothed_logprobs_fused_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(am_probs),
+                      _ptr(lm_probs), _ptr(am_max), _ptr(lm_max), _ptr(lmonly), _ptr(amonly), _ptr(ulog), _ptr(boundary),
+                      int(termination_symbol), float(delay_penalty), cs, ls, a_s, _ptr(px), _ptr(py), _ptr(prod),
+                      B, T, S, C, int(modified), st)
+        else:
+            _lib.call("ftr_smoothed_logprobs_fwd_pen_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
+                      _ptr(lm_max), _ptr(lmonly), _ptr(amonly), _ptr(ulog), _ptr(boundary), int(termination_symbol),
+                      float(delay_penalty), cs, ls, a_s, _ptr(px), _ptr(py), B, T, S, C, int(modified), st)
     saved = (am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0), inv, u, am_dot)
     meta = (int(termination_symbol), int(modified), cs, ls, a_s, count, process_group)
     return px, py, saved, meta
