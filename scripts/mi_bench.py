@@ -27,18 +27,19 @@ def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
     gx = torch.empty_like(px); gy = torch.empty_like(py)
     st = torch.cuda.current_stream().cuda_stream
     flush = torch.empty(512 * 1024 * 1024 // 4, device=dev) if cold else None
+    flags = int(os.environ.get("FTR_BENCH_FLAGS", "1"))   # 1 = FTR_MI_WS_CLEAN (what the package passes), 0 = memset per launch
     tf = tb = 0.0
     for i in range(iters + warm):
         if cold: flush.fill_(1.0)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
         if product:
-            _lib.call("ftr_mutual_information_fwd_ws_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), nws, 1, _ptr(ans), B, S, T, 0, st)
+            _lib.call("ftr_mutual_information_fwd_ws_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), nws, flags, _ptr(ans), B, S, T, 0, st)
         else:
             _lib.call("ftr_mutual_information_fwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(ans), B, S, T, 0, st)
         e[1].record()
         if product:
-            _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), nws, 1, None, _ptr(gx), _ptr(gy), None, 0, B, S, T, 0, st)
+            _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), nws, flags, None, _ptr(gx), _ptr(gy), None, 0, B, S, T, 0, st)
         else:
             _lib.call("ftr_mutual_information_bwd_f32", _ptr(px), _ptr(py), _ptr(bd), _ptr(ws), _ptr(pg), _ptr(gx), _ptr(gy), _ptr(ag), 1, B, S, T, 0, st)
         e[2].record()

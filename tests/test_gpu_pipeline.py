@@ -548,3 +548,31 @@ def test_against_committed_golden_fixtures(ft, dev, name):
         pl.backward()
         np.testing.assert_allclose(pl.item(), float(g[f"pruned_loss_r{r}"]), rtol=1e-4)
         assert max_rel(logits.grad.cpu().numpy(), g[f"pruned_logits_grad_r{r}"]) <= tol
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
+@pytest.mark.parametrize("cfg", [(2, 70, 33, 12), (2, 129, 100, 20), (1, 200, 140, 16), (2, 65, 200, 8), (1, 63, 470, 24), (3, 64, 15, 36)])
+def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cfg, monkeypatch):
+    """csrc/simple_fused.hip (f32-MFMA contraction + epilogue in one kernel) against the library-GEMM + epilogue route on
+    shapes that hit every symbol-block count (4 / 7 / 10 / 13 per workgroup), several symbol tiles, ragged frame tiles,
+    boundaries and the penalty; simple and smoothed.  Same -inf pattern, values to 2e-5 (summation order differs)."""
+    B, T, S, C = cfg
+    d = synthetic(11 + S, B, T, S, C, ragged=True)
+    lm, am, sym, bnd = (_t(d[k], dev) for k in ("lm", "am", "symbols", "boundary"))
+    blank = d["termination_symbol"]
+
+    def run():
+        a = ft.get_rnnt_logprobs(lm, am, sym, blank, rnnt_type=rnnt_type, boundary=bnd)
+        b = ft.get_rnnt_logprobs_smoothed(lm, am, sym, blank, lm_only_scale=0.1, am_only_scale=0.2, boundary=bnd, rnnt_type=rnnt_type)
+        l = ft.rnnt_loss_simple(lm, am, sym, blank, boundary=bnd, rnnt_type=rnnt_type, delay_penalty=0.3, reduction="none")
+        return [x.cpu().numpy() for x in (*a, *b, l)]
+
+    fused = run()
+    monkeypatch.setenv("FTR_BUILDER_GEMM", "library")
+    library = run()
+    for f, l in zip(fused, library):
+        assert f.shape == l.shape
+        assert np.array_equal(np.isneginf(f), np.isneginf(l))
+        fin = np.isfinite(l)
+        if fin.any():      # (S > T with the modified type has no path: every loss is -inf)
+            assert np.abs(f[fin] - l[fin]).max() <= 2e-5 * max(1.0, np.abs(l[fin]).max())
