@@ -185,6 +185,9 @@ def algorithmic_bytes(B, T, S, C, r):
         # simple/smoothed builder ("report bytes and flops separately; it is not the headline")
         "ftr_rowmax_exp_f32": 4 * (nam + nlm),                              # mean of the am call and the lm call: read + write
         "ftr_rowmax_exp_sum_f32": 4 * 2 * nlm,
+        "ftr_rowmax_exp_dot_f32": 4 * 2 * nam,                              # am read, am_probs written (+ the dot for free)
+        "ftr_colsum_weighted_f32": 4 * (nam + nlm) // 2,                    # mean of the lm_probs call (fwd) and the am_probs call (bwd)
+        "ftr_rowdot_f32": 4 * nlm,
         "ftr_simple_logprobs_fwd_f32": 4 * (nam + nlm + npy + npx + npy),   # read am, lm, prod; write px, py
         "ftr_smoothed_logprobs_fwd_f32": 4 * (nam + nlm + npy + npx + npy),
         # fused builder: am_probs, lm_probs (+ the am / lm gathers) in, px, py and the product for the backward out;
@@ -372,6 +375,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave rocBLAS' default kernel choice for the three normaliser GEMMs (tf_fast_rnnt.tune_normalizer_gemms)")
+    ap.add_argument("--gemm-choices", default=None, help="file the library-GEMM kernel choices are stored in / reloaded from")
+    ap.add_argument("--no-gemm-search", action="store_true", help="only apply the choices already in --gemm-choices (profiling runs)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-call HIP events on every n-th timed step (1 = every step)")
     ap.add_argument("--first-pass", default=None, choices=["simple", "smoothed"],
@@ -425,7 +430,8 @@ def main():
         # one-off library-GEMM kernel selection for this process (package feature); the selection happens in this extra
         # untimed step, in front of the W warm-up steps
         import tempfile
-        ft.tune_normalizer_gemms(True, os.path.join(tempfile.gettempdir(), f"ftr_bench_gemm_choices_{os.getpid()}.csv"))
+        ft.tune_normalizer_gemms(True, args.gemm_choices or os.path.join(tempfile.gettempdir(), f"ftr_bench_gemm_choices_{os.getpid()}.csv"),
+                                 search=not args.no_gemm_search)
         step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):

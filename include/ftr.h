@@ -284,6 +284,19 @@ int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const in
                                       int termination_symbol, double delay_penalty, float combined_scale,
                                       float lm_only_scale, float am_only_scale, float* px, float* py, int B, int T,
                                       int S, int C, int modified, void* stream);
+/* Batch statistics of the smoothed builder (rnnt_loss.py:1276-1290 and what autodiff replays for them), MI355X
+ * additions that replace four library matrix-vector products:
+ *   ftr_rowmax_exp_dot_f32    ftr_rowmax_exp_f32 that also returns dot[row] = probs[row,:] . dotvec   (am_probs . unigram)
+ *   ftr_rowdot_f32            dot[row] = x[row,:] . v
+ *   ftr_colsum_weighted_f32   out[c] = sum_row w[row] * x[row,c], two deterministic stages through `workspace`
+ *                             (ftr_colsum_weighted_workspace_floats(rows, C) floats)                                  */
+int ftr_rowmax_exp_dot_f32(const float* x, float* probs, float* rowmax, const float* dotvec, float* dot, long long rows,
+                           int C, void* stream);
+int ftr_rowdot_f32(const float* x, const float* v, float* dot, long long rows, int C, void* stream);
+size_t ftr_colsum_weighted_workspace_floats(long long rows, int C);
+int ftr_colsum_weighted_f32(const float* x, const float* w, float* out, float* workspace, size_t workspace_floats,
+                            long long rows, int C, void* stream);
+
 /* The builders with the normaliser contraction inside the kernel (f32 MFMA, MI355X addition): replaces the batched
  * matmul of rnnt_loss.py:180-182 / :1270-1272 AND the epilogue above in one launch -- the [B,S+1,T] product never goes
  * through memory unless `prod` is non-NULL (the backward's W kernel still reads it).  am_probs / lm_probs / am_max /

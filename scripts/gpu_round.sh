@@ -26,4 +26,6 @@ R=$PWD; cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err; echo "prof exit $?" >> $R/gpurun_out/prof.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_fetch.json 2> $R/gpurun_out/pmc_fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_write.json 2> $R/gpurun_out/pmc_write.err
+rm -rf $R/gpurun_out/prof_c4
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c4 -- python3 $R/bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_bench_c4.json 2> $R/gpurun_out/prof_c4.err; echo "prof c4 exit $?" >> $R/gpurun_out/prof_c4.err
 cd $R; tail -2 gpurun_out/prof.err; ls gpurun_out/pmc_fetch/*/ | head -3

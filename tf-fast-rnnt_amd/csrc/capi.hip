@@ -256,7 +256,7 @@ int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long ro
   FTR_REQUIRE(x && probs && rowmax, "rowmax_exp: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_rowmax_exp(x, probs, rowmax, nullptr, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+  return simple_rowmax_exp(x, probs, rowmax, nullptr, nullptr, nullptr, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_rowmax_exp_sum_f32(const float* x, float* probs, float* rowmax, float* rowsum, long long rows, int C,
@@ -267,7 +267,43 @@ int ftr_rowmax_exp_sum_f32(const float* x, float* probs, float* rowmax, float* r
   FTR_REQUIRE(x && probs && rowmax && rowsum, "rowmax_exp_sum: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return simple_rowmax_exp(x, probs, rowmax, rowsum, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+  return simple_rowmax_exp(x, probs, rowmax, rowsum, nullptr, nullptr, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_rowmax_exp_dot_f32(const float* x, float* probs, float* rowmax, const float* dotvec, float* dot, long long rows,
+                           int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows >= 0 && C >= 0, "rowmax_exp_dot: negative size");
+  if (rows == 0 || C == 0) return FTR_OK;
+  FTR_REQUIRE(x && probs && rowmax && dotvec && dot, "rowmax_exp_dot: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_rowmax_exp(x, probs, rowmax, nullptr, dotvec, dot, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_rowdot_f32(const float* x, const float* v, float* dot, long long rows, int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows >= 0 && C >= 0, "rowdot: negative size");
+  if (rows == 0) return FTR_OK;
+  FTR_REQUIRE(dot && ((x && v) || C == 0), "rowdot: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_rowdot(x, v, dot, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t ftr_colsum_weighted_workspace_floats(long long rows, int C) {
+  return (rows < 0 || C < 0) ? 0 : simple_colsum_workspace_floats((size_t)rows, C);
+}
+
+int ftr_colsum_weighted_f32(const float* x, const float* w, float* out, float* workspace, size_t workspace_floats,
+                            long long rows, int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows >= 0 && C >= 0, "colsum_weighted: negative size");
+  if (C == 0) return FTR_OK;
+  FTR_REQUIRE(out && ((x && w && workspace) || rows == 0), "colsum_weighted: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_colsum_weighted(x, w, out, workspace, workspace_floats, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_simple_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,

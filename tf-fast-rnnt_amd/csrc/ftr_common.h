@@ -100,7 +100,10 @@ int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* r
 int do_pruning_bwd(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm, int B, int T, int S1, int C, int r, hipStream_t st);
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, Scale scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
-int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, size_t rows, int C, hipStream_t st);
+int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, const float* dotvec, float* dot, size_t rows, int C, hipStream_t st);
+int simple_rowdot(const float* x, const float* v, float* dot, size_t rows, int C, hipStream_t st);
+size_t simple_colsum_workspace_floats(size_t rows, int C);
+int simple_colsum_weighted(const float* x, const float* w, float* out, float* ws, size_t ws_floats, size_t rows, int C, hipStream_t st);
 int simple_logprobs_fwd(const float* am, const float* lm, const int32_t* symbols, const float* prod, const float* am_max, const float* lm_max, const int32_t* boundary, int blank, double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog, float cs, float ls, float as, float* px, float* py, int B, int T, int S, int C, int modified, hipStream_t st);
 int simple_logprobs_bwd_w(const float* gpx, const float* gpy, Scale scale, const float* prod, const int32_t* boundary, float* W, float* rsx, float* rsy, float cs, int B, int T, int S, int modified, hipStream_t st);
 int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* damp, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);

@@ -31,39 +31,115 @@ constexpr int kTTnarrow = 16;                    // above FTR_TT_NARROW_ABOVE co
 __device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
-// probs[row, :] = exp(x[row, :] - max(x[row, :])), rowmax[row] = max.  One wave per row.
+// probs[row, :] = exp(x[row, :] - max(x[row, :])), rowmax[row] = max; optionally rowsum[row] = sum of the row of probs
+// and dot[row] = probs[row, :] . dotvec (the am-only normaliser of the smoothed builder, rnnt_loss.py:1281-1286, taken
+// while the row is in registers instead of a second pass over the [B*T, C] matrix).  One wave per row.
 template <bool VEC>
 __global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict__ probs,
-                                  float* __restrict__ rowmax, float* __restrict__ rowsum, size_t rows, int C) {
+                                  float* __restrict__ rowmax, float* __restrict__ rowsum,
+                                  const float* __restrict__ dotvec, float* __restrict__ dot, size_t rows, int C) {
   const int lane = threadIdx.x & 63;
   const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + row * C;
   float* pr = probs + row * C;
   float m = -INFINITY;
+  float sum = 0.0f, dsum = 0.0f;
   if (VEC) {
     const f4u* x4 = reinterpret_cast<const f4u*>(xr);
     f4u* p4 = reinterpret_cast<f4u*>(pr);
+    const f4u* d4 = reinterpret_cast<const f4u*>(dotvec);
     const int n4 = C >> 2;
     for (int i = lane; i < n4; i += 64) { const f4 v = x4[i]; m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); }
     m = wave_max(m);
-    float sum = 0.0f;
     for (int i = lane; i < n4; i += 64) {
       const f4 v = x4[i];
       f4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = expf(v[e] - m); sum += o[e]; }
+      if (dotvec) { const f4 dv = d4[i]; dsum += (o[0] * dv[0] + o[1] * dv[1]) + (o[2] * dv[2] + o[3] * dv[3]); }
       p4[i] = o;
     }
-    if (rowsum) { sum = wave_sum(sum); if (lane == 0) rowsum[row] = sum; }
   } else {
     for (int i = lane; i < C; i += 64) m = fmaxf(m, xr[i]);
     m = wave_max(m);
-    float sum = 0.0f;
-    for (int i = lane; i < C; i += 64) { const float o = expf(xr[i] - m); pr[i] = o; sum += o; }
-    if (rowsum) { sum = wave_sum(sum); if (lane == 0) rowsum[row] = sum; }
+    for (int i = lane; i < C; i += 64) { const float o = expf(xr[i] - m); pr[i] = o; sum += o; if (dotvec) dsum += o * dotvec[i]; }
   }
+  if (rowsum) { sum = wave_sum(sum); if (lane == 0) rowsum[row] = sum; }
+  if (dotvec) { dsum = wave_sum(dsum); if (lane == 0) dot[row] = dsum; }
   if (lane == 0) rowmax[row] = m;
+}
+
+// dot[row] = x[row, :] . v.  One wave per row.
+template <bool VEC>
+__global__ void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ v, float* __restrict__ dot, size_t rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  float acc = 0.0f;
+  if (VEC) {
+    const f4u* x4 = reinterpret_cast<const f4u*>(xr);
+    const f4u* v4 = reinterpret_cast<const f4u*>(v);
+    for (int i = lane; i < (C >> 2); i += 64) { const f4 a = x4[i], b = v4[i]; acc += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
+  } else {
+    for (int i = lane; i < C; i += 64) acc += xr[i] * v[i];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dot[row] = acc;
+}
+
+// out[c] = sum_row w[row] * x[row, c] in two deterministic stages (fixed summation order, no atomics): each workgroup
+// folds a slab of kColsumSlab rows for a strip of columns (one 16-byte piece per thread and row: a row of a strip is one
+// contiguous 4 KB read), a second launch adds the slabs up in order.  (rocBLAS' gemv for this shape -- [64000 x 1024]^T
+// times a vector -- takes 1.1 ms on MI355X; this takes the time of reading the matrix once.)
+constexpr int kColsumSlab = 64;
+template <bool VEC>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ partial, size_t rows, int C) {
+  const size_t r0 = (size_t)blockIdx.x * kColsumSlab;
+  const size_t r1 = r0 + kColsumSlab < rows ? r0 + kColsumSlab : rows;
+  if (VEC) {
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    size_t r = r0;
+    for (; r + 16 <= r1; r += 16) {     // sixteen independent 16-byte loads in flight per lane
+      f4 v[16]; float ww[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { v[u] = *reinterpret_cast<const f4u*>(x + (r + u) * C + c); ww[u] = w[r + u]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u] * ww[u];
+    }
+    for (; r < r1; ++r) acc += *reinterpret_cast<const f4u*>(x + r * C + c) * w[r];
+    *reinterpret_cast<f4u*>(partial + (size_t)blockIdx.x * C + c) = acc;
+  } else {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.0f;
+    for (size_t r = r0; r < r1; ++r) acc += x[r * C + c] * w[r];
+    partial[(size_t)blockIdx.x * C + c] = acc;
+  }
+}
+// 64 columns x 4 slab groups per workgroup; the four partial sums of a column are added in a fixed order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslab, int C) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (nslab + 3) / 4;
+  const int i0 = gq * per, i1 = min(i0 + per, nslab);
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  if (c < C) {
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+      a0 += partial[(size_t)i * C + c]; a1 += partial[(size_t)(i + 1) * C + c];
+      a2 += partial[(size_t)(i + 2) * C + c]; a3 += partial[(size_t)(i + 3) * C + c];
+    }
+    for (; i < i1; ++i) a0 += partial[(size_t)i * C + c];
+  }
+  part[gq][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (gq == 0 && c < C) out[c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 // grid (ceil(T1 / TT), B); block 256 = (256/TT) row-groups x TT frames.  LDS: am tile [TT][C+1].
@@ -351,13 +427,41 @@ __global__ void simple_bwd_lm_kernel(const float* __restrict__ dlmp, const float
 
 }  // namespace
 
-int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, size_t rows, int C, hipStream_t st) {
+int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, const float* dotvec, float* dot,
+                      size_t rows, int C, hipStream_t st) {
   if (rows == 0 || C == 0) return FTR_OK;
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
-  if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, rows, C);
-  else hipLaunchKernelGGL(rowmax_exp_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, rows, C);
+  if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, dotvec, dot, rows, C);
+  else hipLaunchKernelGGL(rowmax_exp_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, dotvec, dot, rows, C);
   return check_launch("rowmax_exp");
+}
+
+int simple_rowdot(const float* x, const float* v, float* dot, size_t rows, int C, hipStream_t st) {
+  if (rows == 0) return FTR_OK;
+  const int wpb = 4;
+  const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
+  if ((C & 3) == 0) hipLaunchKernelGGL(rowdot_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, v, dot, rows, C);
+  else hipLaunchKernelGGL(rowdot_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, v, dot, rows, C);
+  return check_launch("rowdot");
+}
+
+size_t simple_colsum_workspace_floats(size_t rows, int C) { return ((rows + kColsumSlab - 1) / kColsumSlab) * (size_t)C; }
+
+int simple_colsum_weighted(const float* x, const float* w, float* out, float* ws, size_t ws_floats, size_t rows, int C,
+                           hipStream_t st) {
+  if (C == 0) return FTR_OK;
+  const size_t nslab = (rows + kColsumSlab - 1) / kColsumSlab;
+  if (ws_floats < nslab * (size_t)C) { set_error("colsum_weighted: workspace of %zu floats, %zu needed", ws_floats, nslab * (size_t)C); return FTR_ERR_INVALID_ARG; }
+  if (nslab > 0x7fffffff) { set_error("colsum_weighted: too many rows"); return FTR_ERR_UNSUPPORTED; }
+  if (nslab > 0) {
+    if ((C & 3) == 0) hipLaunchKernelGGL(colsum_partial_kernel<true>, dim3((unsigned)nslab, (C / 4 + 255) / 256), dim3(256), 0, st, x, w, ws, rows, C);
+    else hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3((unsigned)nslab, (C + 255) / 256), dim3(256), 0, st, x, w, ws, rows, C);
+    int rc = check_launch("colsum_weighted (partial)");
+    if (rc != FTR_OK) return rc;
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, ws, out, (int)nslab, C);
+  return check_launch("colsum_weighted (final)");
 }
 
 static int tile_lds_ok(size_t lds, const char* what) {

@@ -55,6 +55,10 @@ _SIGNATURES = {
     "ftr_smoothed_logprobs_fwd_pen_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _f, _f, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_bwd_w_scaled_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_ip, _f, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_bwd_am_scaled_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_ip, _c_ip, _i, _f, _c_fp, _c_fp, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_rowmax_exp_dot_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
+    "ftr_rowdot_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
+    "ftr_colsum_weighted_workspace_floats": (ctypes.c_size_t, [ctypes.c_longlong, _i]),
+    "ftr_colsum_weighted_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_size_t, ctypes.c_longlong, _i, _c_st]),
     "ftr_simple_logprobs_fused_supported": (_i, [_i]),
     "ftr_simple_logprobs_fused_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_fused_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _f, _f, _f, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),

@@ -34,18 +34,21 @@ _NEG_INF = float("-inf")
 _TINY = 1.401298464324817e-45
 
 
-def tune_normalizer_gemms(enable: bool = True, filename: Optional[str] = None) -> None:
-    """The three dense contractions of the simple / smoothed builders (normalisers = lm_probs @ am_probs^T and its two
-    transposes in the backward, rnnt_loss.py:180-182) are library f32 GEMMs.  rocBLAS' default kernel choice for these
-    shapes runs at 62-77 TFLOP/s on MI355X; letting the library time its candidate kernels once per shape (PyTorch's
-    TunableOp over rocBLAS / hipBLASLt) gives ~100 TFLOP/s (104/90/84 -> 65/62/60 us at B=32 T=1000 S=200 C=500).
-    Process-wide switch (it affects every torch GEMM of the process); the first call of each new shape is slow and
-    must not happen inside a stream capture.  `filename`: where the choices are stored / reloaded from."""
+def tune_normalizer_gemms(enable: bool = True, filename: Optional[str] = None, search: bool = True) -> None:
+    """The dense contractions of the simple / smoothed builders that stay library f32 GEMMs (the two transposes of the
+    normaliser product in the backward; also the forward one when C % 4 != 0, rnnt_loss.py:180-182) run at 62-77 TFLOP/s
+    with rocBLAS' default kernel choice for these shapes on MI355X; letting the library time its candidate kernels once
+    per shape (PyTorch's TunableOp over rocBLAS / hipBLASLt) gives ~100 TFLOP/s (104/90/84 -> 65/62/60 us at B=32 T=1000
+    S=200 C=500).  Process-wide switch (it affects every torch GEMM of the process); with ``search`` the first call of
+    each new shape is slow and must not happen inside a stream capture.  ``filename``: where the choices are stored and
+    reloaded from; ``search=False`` only applies the choices already in that file."""
     import torch.cuda.tunable as tunable
     tunable.enable(bool(enable))
-    tunable.tuning_enable(bool(enable))
+    tunable.tuning_enable(bool(enable) and bool(search))
     if filename is not None:
         tunable.set_filename(filename)
+        if enable and os.path.exists(filename):
+            tunable.read_file(filename)
 
 
 def _check_type(rnnt_type: str) -> None:
@@ -682,6 +685,15 @@ def rnnt_loss_pruned(
                              float(delay_penalty) if delay_penalty > 0.0 else 0.0, code)
 
 
+def _colsum_weighted(x: torch.Tensor, w: torch.Tensor, rows: int, C: int, st) -> torch.Tensor:
+    """out[c] = sum_row w[row] * x[row, c] on the native two-stage kernel (deterministic)."""
+    n = _lib.lib().ftr_colsum_weighted_workspace_floats(rows, C)
+    ws = torch.empty((max(n, 1),), dtype=torch.float32, device=x.device)
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    _lib.call("ftr_colsum_weighted_f32", _ptr(x), _ptr(w), _ptr(out), _ptr(ws), n, rows, C, st)
+    return out
+
+
 def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale, am_only_scale,
                       process_group, delay_penalty):
     """Forward of the smoothed builder on the native kernels (rnnt_loss.py:1265-1365; with the penalty block :1461-1478
@@ -702,20 +714,21 @@ def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, l
     py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         st = _stream_ptr(amc)
-        _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)           # :1265-1268
         _lib.call("ftr_rowmax_exp_sum_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), _ptr(lm_sum),
                   B * (S + 1), C, st)                                                                   # :1276-1278
-        fused = _use_fused_builder(C)
-        prod = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev) if fused else \
-            torch.bmm(lm_probs, am_probs.transpose(1, 2))                                               # :1270-1272
-        inv = 1.0 / lm_sum                                                                              # [B,S+1]
-        ratio_sum = torch.mv(lm_probs.reshape(-1, C).t(), inv.reshape(-1))                               # [C]
+        inv = (1.0 / lm_sum).contiguous()                                                               # [B,S+1]
+        ratio_sum = _colsum_weighted(lm_probs, inv, B * (S + 1), C, st)                                 # [C]
         count = float(B * (S + 1))
         if process_group is not None:
             torch.distributed.all_reduce(ratio_sum, group=process_group)
             count *= torch.distributed.get_world_size(process_group)
-        u = ratio_sum / count + _TINY                                                                   # :1279-1280
-        am_dot = torch.mv(am_probs.reshape(-1, C), u)                                                   # [B*T]
+        u = (ratio_sum / count + _TINY).contiguous()                                                    # :1279-1280
+        # am_probs, am_max and am_probs . u in one pass over am (:1265-1268, :1281-1286)
+        am_dot = torch.empty((B * T,), dtype=torch.float32, device=dev)
+        _lib.call("ftr_rowmax_exp_dot_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), _ptr(u), _ptr(am_dot), B * T, C, st)
+        fused = _use_fused_builder(C)
+        prod = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev) if fused else \
+            torch.bmm(lm_probs, am_probs.transpose(1, 2))                                               # :1270-1272
         amonly = (am_dot.log().reshape(B, T) + am_max).contiguous()                                     # :1281-1286
         ulog = u.log().contiguous()                                                                     # :1287
         lmonly = (lm_sum.log() + lm_max).contiguous()                                                   # :1288-1290
@@ -759,7 +772,7 @@ def _smoothed_backward(saved, has_boundary, meta, gpx, gpy, scale=None, stride=0
                   _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R),
                   _ptr(d_am), B, T, S, C, modified, st)
         # d u: through amonly_norm and through ulog
-        du = torch.mv(am_probs.reshape(-1, C).t(), R.reshape(-1))
+        du = _colsum_weighted(am_probs, R, B * T, C, st)
         gul = torch.zeros((C,), dtype=torch.float32, device=dev)
         if S > 0:
             gul.index_add_(0, _i64(symbols).reshape(-1), rsx[:, :S].reshape(-1))
@@ -768,7 +781,9 @@ def _smoothed_backward(saved, has_boundary, meta, gpx, gpy, scale=None, stride=0
         if group is not None:
             torch.distributed.all_reduce(du, group=group)
         gu = (du / count).contiguous()
-        dotq = torch.mv(lm_probs.reshape(-1, C), gu).reshape(B, S + 1) * inv
+        dotq = torch.empty((B, S + 1), dtype=torch.float32, device=dev)
+        _lib.call("ftr_rowdot_f32", _ptr(lm_probs), _ptr(gu), _ptr(dotq), B * (S + 1), C, st)
+        dotq = dotq * inv
         arow = ((-ls) * (rsx + rsy) - dotq) * inv
         arow = arow.contiguous()
         _lib.call("ftr_smoothed_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx),
