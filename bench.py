@@ -151,6 +151,7 @@ CALL_KERNELS = {
     "ftr_rowmax_exp_f32": ["rowmax_exp_kernel<true>"],
     "ftr_simple_logprobs_fwd_f32": ["simple_fwd_kernel<false, 16>"],
     "ftr_simple_logprobs_fused_fwd_f32": ["simple_fused_fwd_kernel<false, false, 13>"],
+    "ftr_simple_logprobs_fused_bwd_am_f32": ["simple_fused_bwd_am_kernel<false, 16>"],
     "ftr_simple_logprobs_bwd_w_f32": ["simple_bwd_w_kernel<false>"],
     "ftr_simple_logprobs_bwd_am_f32": ["simple_bwd_am_kernel<false>"],
     "ftr_simple_logprobs_bwd_lm_f32": ["simple_bwd_lm_kernel"],
@@ -202,6 +203,9 @@ def algorithmic_bytes(B, T, S, C, r):
         "ftr_simple_logprobs_bwd_am_f32": 4 * (npx + npy + 3 * nam),        # read gpx, gpy, damp, am_probs; write d am
         "ftr_smoothed_logprobs_bwd_am_f32": 4 * (npx + npy + 3 * nam),
         "ftr_simple_logprobs_bwd_lm_f32": 4 * 3 * nlm,
+        # fused d am: g_px, g_py, prod, lm_probs, am_probs in, d am out (g_px read again by the scatter pass)
+        "ftr_simple_logprobs_fused_bwd_am_f32": 4 * (2 * npx + 2 * npy + nlm + 2 * nam),
+        "ftr_smoothed_logprobs_fused_bwd_am_f32": 4 * (2 * npx + 2 * npy + nlm + 2 * nam),
         "ftr_smoothed_logprobs_bwd_lm_f32": 4 * 3 * nlm,
         "ftr_do_pruning_bwd_f32": 2 * N + 4 * (nam + nlm + B * T * r),      # read both pruned gradients, write d am, d lm
         "ftr_do_pruning_bwd_ws_f32": N + 4 * (nam + nlm + B * T * r),       # the joiner's gradient is ONE tensor: read once

@@ -314,6 +314,20 @@ int ftr_smoothed_logprobs_fused_fwd_f32(const float* am, const float* lm, const 
                                         const int32_t* boundary, int termination_symbol, double delay_penalty,
                                         float combined_scale, float lm_only_scale, float am_only_scale, float* px,
                                         float* py, float* prod, int B, int T, int S, int C, int modified, void* stream);
+/* Backward towards am with the W^T . lm_probs contraction inside the kernel (f32 MFMA): replaces one of the two backward
+ * matmuls AND ftr_*_logprobs_bwd_am_*: W is formed from g_px, g_py and prod while staging, the scatter by symbol runs as a
+ * second small MFMA contraction against a one-hot operand, `damp` [B,T,C] never exists.  Scale arguments as in the _scaled
+ * forms above.  Requires C % 4 == 0 (ftr_simple_logprobs_fused_supported). */
+int ftr_simple_logprobs_fused_bwd_am_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                         float scale_mul, const float* prod, const float* lm_probs, const float* am_probs,
+                                         const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                         float* d_am, int B, int T, int S, int C, int modified, void* stream);
+int ftr_smoothed_logprobs_fused_bwd_am_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                           float scale_mul, const float* prod, const float* lm_probs,
+                                           const float* am_probs, const int32_t* symbols, const int32_t* boundary,
+                                           int termination_symbol, float combined_scale, float direct_scale,
+                                           const float* unigram, const float* am_dot, float am_only_scale, float* R,
+                                           float* d_am, int B, int T, int S, int C, int modified, void* stream);
 int ftr_smoothed_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
                                            float scale_mul, const float* prod, const int32_t* boundary,
                                            float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,

@@ -576,3 +576,35 @@ def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cf
         fin = np.isfinite(l)
         if fin.any():      # (S > T with the modified type has no path: every loss is -inf)
             assert np.abs(f[fin] - l[fin]).max() <= 2e-5 * max(1.0, np.abs(l[fin]).max())
+
+
+@pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
+@pytest.mark.parametrize("cfg", [(2, 70, 33, 12), (2, 129, 100, 20), (1, 200, 140, 260), (2, 65, 200, 8), (3, 64, 15, 36)])
+def test_fused_d_am_kernel_matches_library_gemm_route(ft, dev, rnnt_type, cfg, monkeypatch):
+    """The opt-in fused backward towards am (FTR_BUILDER_BWD=fused: W^T lm_probs as MFMA inside the kernel, scatter by
+    symbol as a one-hot MFMA contraction) against the default route (library GEMM + epilogue kernel): gradients of the
+    simple and of the smoothed loss w.r.t. am and lm, with boundaries and a non-uniform upstream gradient."""
+    B, T, S, C = cfg
+    d = synthetic(23 + S, B, T, S, C, ragged=True)
+    sym, bnd = _t(d["symbols"], dev), _t(d["boundary"], dev)
+    blank = d["termination_symbol"]
+    wts = torch.linspace(0.5, 1.5, B, device=dev)
+
+    def grads():
+        out = []
+        for fn in (lambda lm, am: ft.rnnt_loss_simple(lm, am, sym, blank, boundary=bnd, rnnt_type=rnnt_type, reduction="none"),
+                   lambda lm, am: ft.rnnt_loss_smoothed(lm, am, sym, blank, lm_only_scale=0.1, am_only_scale=0.2, boundary=bnd,
+                                                        rnnt_type=rnnt_type, reduction="none")):
+            lm = _t(d["lm"], dev).requires_grad_(True); am = _t(d["am"], dev).requires_grad_(True)
+            loss = fn(lm, am)
+            fin = torch.isfinite(loss)
+            (loss[fin] * wts[fin]).sum().backward()
+            out += [am.grad.cpu().numpy(), lm.grad.cpu().numpy()]
+        return out
+
+    library = grads()
+    monkeypatch.setenv("FTR_BUILDER_BWD", "fused")
+    fused = grads()
+    for f, l in zip(fused, library):
+        assert np.isfinite(f).all()
+        assert np.abs(f - l).max() <= 2e-5 * max(1.0, np.abs(l).max())

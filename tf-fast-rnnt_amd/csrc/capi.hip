@@ -515,6 +515,38 @@ int ftr_smoothed_logprobs_fused_fwd_f32(const float* am, const float* lm, const 
   return simple_fused_fwd(am, lm, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol, delay_penalty, lmonly_norm, amonly_norm, unigram_log, combined_scale, lm_only_scale, am_only_scale, px, py, prod, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ftr_simple_logprobs_fused_bwd_am_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                         float scale_mul, const float* prod, const float* lm_probs, const float* am_probs,
+                                         const int32_t* symbols, const int32_t* boundary, int termination_symbol,
+                                         float* d_am, int B, int T, int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "simple_logprobs_fused_bwd_am: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "simple_logprobs_fused_bwd_am: bad termination_symbol");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "simple_logprobs_fused_bwd_am: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && prod && lm_probs && am_probs && d_am && (gpx || S == 0) && (symbols || S == 0), "simple_logprobs_fused_bwd_am: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_fused_bwd_am(gpx, gpy, Scale{scale, scale_stride, scale_mul}, prod, lm_probs, am_probs, symbols, boundary, termination_symbol, 1.0f, 1.0f, nullptr, nullptr, 0.0f, nullptr, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_smoothed_logprobs_fused_bwd_am_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
+                                           float scale_mul, const float* prod, const float* lm_probs,
+                                           const float* am_probs, const int32_t* symbols, const int32_t* boundary,
+                                           int termination_symbol, float combined_scale, float direct_scale,
+                                           const float* unigram, const float* am_dot, float am_only_scale, float* R,
+                                           float* d_am, int B, int T, int S, int C, int modified, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && C >= 1, "smoothed_logprobs_fused_bwd_am: bad sizes");
+  FTR_REQUIRE(termination_symbol >= 0 && termination_symbol < C, "smoothed_logprobs_fused_bwd_am: bad termination_symbol");
+  FTR_REQUIRE(scale_stride == 0 || scale_stride == 1, "smoothed_logprobs_fused_bwd_am: scale_stride must be 0 or 1");
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(gpy && prod && lm_probs && am_probs && d_am && unigram && am_dot && R && (gpx || S == 0) && (symbols || S == 0), "smoothed_logprobs_fused_bwd_am: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_fused_bwd_am(gpx, gpy, Scale{scale, scale_stride, scale_mul}, prod, lm_probs, am_probs, symbols, boundary, termination_symbol, combined_scale, direct_scale, unigram, am_dot, am_only_scale, R, d_am, B, T, S, C, modified, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ftr_smoothed_logprobs_bwd_w_scaled_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
                                            float scale_mul, const float* prod, const int32_t* boundary,
                                            float combined_scale, float* W, float* rsx, float* rsy, int B, int T, int S,

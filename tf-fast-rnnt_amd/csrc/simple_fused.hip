@@ -206,6 +206,216 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------- backward: d am
+// d am[b,t,c] = am_probs[b,t,c] * sum_s W[b,s,t] lm_probs[b,s,c]  +  kdir * (sum_{s: sym(s) = c} gx[b,s,t] + [c = blank] sum_s gy[b,s,t])
+//               (+ smoothed: am_probs[b,t,c] * u[c] * R[b,t],  R = -as * colsum_s(gx + gy) / (am_probs . u))
+// with W = -cs (gx + gy) / (prod + tiny), gx = g_px masked where the forward wrote -inf, both times the upstream scale
+// (what TF autodiff replays for rnnt_loss.py:180-221 / :1296-1365 towards am).  Round 1 ran this as W kernel -> library GEMM
+// (damp [B,T,C] through memory) -> scatter/epilogue kernel.  Here one workgroup owns 64 frames x 16 NCB columns and loops
+// over the symbol rows twice with the SAME accumulators:
+//   pass 1  acc[c,t] += lm_probs[s,c] * W[s,t]          (MFMA; W formed from g_px, g_py, prod while staging)
+//           acc = am_probs * (acc + u R)                (column sums for R and the blank term were taken while staging)
+//   pass 2  acc[c,t] += onehot(sym(s) = c) * kdir gx[s,t]   (the scatter by symbol as a second small MFMA contraction:
+//                                                        exact 0/1 products, no LDS scatter tile, no atomics)
+// MFMA roles: M = columns, N = frames, so a lane's accumulator quad is four consecutive columns of one frame: am_probs is
+// read and d am written 16 bytes per lane.  C % 4 == 0.
+constexpr int kBT = 64;                           // frames per workgroup
+constexpr int kBS = 16;                           // symbol rows per staged chunk (four MFMA k-steps)
+
+template <int NCB>
+__host__ __device__ constexpr size_t fused_bwd_lds_bytes() {
+  return sizeof(float) * (2 * kBS * (16 * NCB + 4) + 2 * kBS * (kBT + 4) + 2 * kBS * kBT) + sizeof(int) * 2 * kBS;
+}
+
+template <bool MOD, int NCB>
+__global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
+    const float* __restrict__ gpx, const float* __restrict__ gpy, const Scale scale, const float* __restrict__ prod,
+    const float* __restrict__ lm_probs, const float* __restrict__ am_probs, const int32_t* __restrict__ symbols,
+    const int32_t* __restrict__ boundary, int blank, float cs, float kdir, const float* __restrict__ uvec,
+    const float* __restrict__ amdot, float as, float* __restrict__ Rout, float* __restrict__ d_am, int T, int S, int C) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CT = 16 * NCB, LDC = CT + 4, LDT = kBT + 4;
+  float* lmT = smem;                               // [2][kBS][LDC]   lm_probs rows of the chunk
+  float* wT = lmT + 2 * kBS * LDC;                 // [2][kBS][LDT]   W (pass 1) / kdir * gx (pass 2) rows of the chunk
+  float* csb = wT + 2 * kBS * LDT;                 // [2][kBS][kBT]   partial column sums (x, y) per staging row class
+  int* symL = reinterpret_cast<int*>(csb + 2 * kBS * kBT);   // [2][kBS]
+  const int b = blockIdx.z, t0 = blockIdx.x * kBT, c0 = blockIdx.y * CT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T1 = MOD ? T : T + 1;
+  const int te = boundary ? boundary[4 * b + 3] : T;
+  const float sc = scale.at(b);
+  const float* gxb = gpx + (size_t)b * S * T1;
+  const float* gyb = gpy + (size_t)b * (S + 1) * T;
+  const float* prb = prod + (size_t)b * (S + 1) * T;
+  const float* lmb = lm_probs + (size_t)b * (S + 1) * C;
+  const int nk = (S + 1 + kBS - 1) / kBS;
+
+  // ---- staging plan.  lm tile: piece e = tid + 256 u (u < NL) = 4 columns of one of the chunk's rows.
+  constexpr int NL = (kBS * CT / 4 + 255) / 256;
+  // W / x tile: row tid / 16 of the chunk, frames t0 + 4 (tid % 16) .. +3
+  const int wrow = tid >> 4, wt = t0 + 4 * (tid & 15);
+  const bool wthread = tid < kBS * (kBT / 4);
+  auto load_lm = [&](int kc, f4 (&v)[NL]) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + 256 * u, row = e / (CT / 4), c = c0 + 4 * (e % (CT / 4));
+      const int s = kc * kBS + row;
+      v[u] = f4{0.f, 0.f, 0.f, 0.f};
+      if (e < kBS * CT / 4 && s <= S && c < C) v[u] = *reinterpret_cast<const f4*>(lmb + (size_t)s * C + c);
+    }
+  };
+  auto store_lm = [&](int buf, const f4 (&v)[NL]) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + 256 * u, row = e / (CT / 4), c4 = e % (CT / 4);
+      if (e < kBS * CT / 4) *reinterpret_cast<f4*>(lmT + (buf * kBS + row) * LDC + 4 * c4) = v[u];
+    }
+  };
+  // masked, scaled gradients of the chunk row this thread stages: x = g_px (0 where the forward wrote -inf), y = g_py
+  auto load_xy = [&](int kc, f4& x, f4& y, f4& pr, bool want_pr) {
+    const int s = kc * kBS + wrow;
+    x = f4{0.f, 0.f, 0.f, 0.f}; y = x; pr = f4{1.f, 1.f, 1.f, 1.f};
+    if (!wthread || s > S || wt >= T) return;
+    if (wt + 3 < T) {
+      if (s < S) x = *reinterpret_cast<const f4u*>(gxb + (size_t)s * T1 + wt);
+      y = *reinterpret_cast<const f4u*>(gyb + (size_t)s * T + wt);
+      if (want_pr) pr = *reinterpret_cast<const f4u*>(prb + (size_t)s * T + wt);
+    } else {
+      for (int e = 0; e < 4; ++e) if (wt + e < T) {
+        if (s < S) x[e] = gxb[(size_t)s * T1 + wt + e];
+        y[e] = gyb[(size_t)s * T + wt + e];
+        if (want_pr) pr[e] = prb[(size_t)s * T + wt + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[e] *= sc; y[e] *= sc;
+      if (!MOD && wt + e == te) x[e] = 0.0f;
+    }
+  };
+
+  v4f acc[NCB];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int fk = lane >> 4, fn = lane & 15;        // MFMA fragment coordinates of this lane: k row, m / n index
+
+  // =================================================================== pass 1: acc[c,t] += lm_probs[s,c] W[s,t]
+  f4 sx = {0.f, 0.f, 0.f, 0.f}, sy = {0.f, 0.f, 0.f, 0.f};   // column sums of this thread's row class
+  {
+    f4 lv[NL], x, y, pr;
+    load_lm(0, lv); load_xy(0, x, y, pr, true);
+    auto store_w = [&](int buf) {
+      if (!wthread) return;
+      f4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[e] = -cs * (x[e] + y[e]) / (pr[e] + kTinyF); }
+      sx += x; sy += y;
+      *reinterpret_cast<f4*>(wT + (buf * kBS + wrow) * LDT + 4 * (tid & 15)) = w;
+    };
+    store_lm(0, lv); store_w(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < nk) { load_lm(kc + 1, lv); load_xy(kc + 1, x, y, pr, true); }
+#pragma unroll
+      for (int kk = 0; kk < kBS / 4; ++kk) {
+        const float bw = wT[(buf * kBS + 4 * kk + fk) * LDT + 16 * wave + fn];
+        const float* arow = lmT + (buf * kBS + 4 * kk + fk) * LDC + fn;
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * i], bw, acc[i], 0, 0, 0);
+      }
+      if (kc + 1 < nk) { store_lm(buf ^ 1, lv); store_w(buf ^ 1); }
+      __syncthreads();
+    }
+  }
+  // ---- column sums over s of x and y for this lane's frame (blank term, R), then acc = am_probs * (acc + u R)
+  if (wthread) {
+    *reinterpret_cast<f4*>(csb + (0 * kBS + wrow) * kBT + 4 * (tid & 15)) = sx;
+    *reinterpret_cast<f4*>(csb + (1 * kBS + wrow) * kBT + 4 * (tid & 15)) = sy;
+  }
+  __syncthreads();
+  const int tl = 16 * wave + fn, t = t0 + tl;
+  float cx = 0.0f, cy = 0.0f;
+#pragma unroll
+  for (int r8 = 0; r8 < kBS; ++r8) { cx += csb[(0 * kBS + r8) * kBT + tl]; cy += csb[(1 * kBS + r8) * kBT + tl]; }
+  const bool tok = t < T;
+  float R = 0.0f;
+  if (uvec && tok) {
+    R = -as * (cx + cy) / amdot[(size_t)b * T + t];
+    if (blockIdx.y == 0 && fk == 0) Rout[(size_t)b * T + t] = R;
+  }
+  const float* aprow = am_probs + ((size_t)b * T + (tok ? t : 0)) * C;
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int c = c0 + 16 * i + 4 * fk;
+    f4 ap = {0.f, 0.f, 0.f, 0.f};
+    if (tok && c < C) ap = *reinterpret_cast<const f4*>(aprow + c);
+    if (uvec) {
+      f4 uv = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) uv = *reinterpret_cast<const f4*>(uvec + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = ap[j] * (acc[i][j] + uv[j] * R);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = ap[j] * acc[i][j];
+    }
+  }
+  // =================================================================== pass 2: acc[c,t] += [sym(s) = c] kdir gx[s,t]
+  {
+    f4 x, y, pr;
+    int symr = -1;
+    auto load_sym = [&](int kc) {
+      symr = -1;
+      if (tid < kBS) { const int s = kc * kBS + tid; if (s < S) symr = min(max(symbols[(size_t)b * S + s], 0), C - 1); }
+    };
+    auto store_x = [&](int buf) {
+      if (wthread) *reinterpret_cast<f4*>(wT + (buf * kBS + wrow) * LDT + 4 * (tid & 15)) = x * kdir;
+      if (tid < kBS) symL[buf * kBS + tid] = symr;
+    };
+    const int nk2 = (S + kBS - 1) / kBS;            // rows s < S only
+    if (nk2 > 0) {
+      load_xy(0, x, y, pr, false); load_sym(0);
+      store_x(0);
+      __syncthreads();
+      for (int kc = 0; kc < nk2; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk2) { load_xy(kc + 1, x, y, pr, false); load_sym(kc + 1); }
+#pragma unroll
+        for (int kk = 0; kk < kBS / 4; ++kk) {
+          const float bx = wT[(buf * kBS + 4 * kk + fk) * LDT + 16 * wave + fn];
+          const int rel = symL[buf * kBS + 4 * kk + fk] - c0 - fn;      // this lane's A element is 1 iff rel == 16 i
+          // only the (at most four) column blocks that a symbol of this k-step falls into do any work (wave-uniform mask)
+          unsigned mask = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int sb = __builtin_amdgcn_readfirstlane(symL[buf * kBS + 4 * kk + q]) - c0;
+            if (sb >= 0 && sb < CT) mask |= 1u << (sb >> 4);
+          }
+#pragma unroll
+          for (int i = 0; i < NCB; ++i)
+            if (mask & (1u << i)) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32((rel == 16 * i) ? 1.0f : 0.0f, bx, acc[i], 0, 0, 0);
+        }
+        if (kc + 1 < nk2) store_x(buf ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+  // ---- blank column, store
+  if (!tok) return;
+  float* drow = d_am + ((size_t)b * T + t) * C;
+  const float colb = kdir * cy;
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    const int c = c0 + 16 * i + 4 * fk;
+    if (c >= C) continue;
+    f4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    if (blank >= c && blank < c + 4) v[blank - c] += colb;
+    *reinterpret_cast<f4*>(drow + c) = v;
+  }
+}
+
 }  // namespace
 
 int simple_fused_supported(int C) { return (C % 4 == 0) ? 1 : 0; }
@@ -248,6 +458,25 @@ int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, c
 #undef FTR_FUSED_NS
 #undef FTR_FUSED_LAUNCH
   return check_launch("simple_logprobs_fused_fwd");
+}
+
+int simple_fused_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* prod, const float* lm_probs,
+                        const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float cs,
+                        float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B,
+                        int T, int S, int C, int modified, hipStream_t st) {
+  if (!simple_fused_supported(C)) { set_error("simple_logprobs_fused_bwd_am: C = %d is not a multiple of 4", C); return FTR_ERR_UNSUPPORTED; }
+  const int blocks = (C + 15) / 16;
+  const int ncb = 16;                                          // column blocks per workgroup (24 / 32 run out of registers at two waves per SIMD)
+  const dim3 grid((T + kBT - 1) / kBT, (blocks + ncb - 1) / ncb, B);
+  if (grid.z > 65535) { set_error("simple_logprobs_fused_bwd_am: B = %d > 65535", B); return FTR_ERR_UNSUPPORTED; }
+#define FTR_FBWD_LAUNCH(MODV, NCBV)                                                                                       \
+  hipLaunchKernelGGL((simple_fused_bwd_am_kernel<MODV, NCBV>), grid, dim3(256), fused_bwd_lds_bytes<NCBV>(), st, gpx, gpy, \
+                     scale, prod, lm_probs, am_probs, symbols, boundary, blank, cs, kdir, uvec, amdot, as, Rout, d_am, T, S, C)
+#define FTR_FBWD_NCB(MODV) FTR_FBWD_LAUNCH(MODV, 16)
+  if (modified) FTR_FBWD_NCB(true); else FTR_FBWD_NCB(false);
+#undef FTR_FBWD_NCB
+#undef FTR_FBWD_LAUNCH
+  return check_launch("simple_logprobs_fused_bwd_am");
 }
 
 }  // namespace ftr

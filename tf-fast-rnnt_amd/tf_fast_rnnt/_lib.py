@@ -62,6 +62,8 @@ _SIGNATURES = {
     "ftr_simple_logprobs_fused_supported": (_i, [_i]),
     "ftr_simple_logprobs_fused_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_fused_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _f, _f, _f, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_simple_logprobs_fused_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_smoothed_logprobs_fused_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _f, _f, _c_fp, _c_fp, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_band_supported": (_i, [_i, _i, _i]),
     "ftr_pruned_band_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_band_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),

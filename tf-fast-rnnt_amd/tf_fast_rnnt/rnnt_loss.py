@@ -75,6 +75,14 @@ def _use_fused_builder(C: int) -> bool:
     return os.environ.get("FTR_BUILDER_GEMM", "fused") != "library" and bool(_lib.lib().ftr_simple_logprobs_fused_supported(int(C)))
 
 
+def _use_fused_builder_bwd(C: int) -> bool:
+    """The fused d am kernel (W^T lm_probs + scatter inside one kernel, csrc/simple_fused.hip) is opt-in
+    (FTR_BUILDER_BWD=fused): at B=32 T=1000 S=200 C=500 it takes 165 us against 63 + 61 us for the tuned library GEMM + the
+    epilogue kernel it replaces (short contraction, K = S+1: its operand staging is latency bound), so the library route
+    stays the default for the backward."""
+    return os.environ.get("FTR_BUILDER_BWD", "library") == "fused" and _use_fused_builder(C)
+
+
 def _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, blank, delay_penalty, px, py,
                     B, T, S, C, modified, st):
     """normalisers + px / py of get_rnnt_logprobs (rnnt_loss.py:180-221): one fused launch, or library GEMM + epilogue.
@@ -138,9 +146,14 @@ class _SimpleLogprobs(torch.autograd.Function):
             _lib.call("ftr_simple_logprobs_bwd_w_f32", _ptr(gpx), _ptr(gpy), _ptr(prod), _ptr(boundary), _ptr(W),
                       _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
             dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-            damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
-            _lib.call("ftr_simple_logprobs_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(damp), _ptr(am_probs), _ptr(symbols),
-                      _ptr(boundary), blank, _ptr(d_am), B, T, S, C, modified, st)
+            if _use_fused_builder_bwd(C):                       # W^T lm_probs inside the d am kernel (opt-in)
+                _lib.call("ftr_simple_logprobs_fused_bwd_am_f32", _ptr(gpx), _ptr(gpy), None, 0, 1.0, _ptr(prod),
+                          _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
+                          modified, st)
+            else:
+                damp = torch.bmm(W.transpose(1, 2), lm_probs)   # [B,T,C]
+                _lib.call("ftr_simple_logprobs_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(damp), _ptr(am_probs),
+                          _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C, modified, st)
             _lib.call("ftr_simple_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx), _ptr(rsy),
                       blank, _ptr(d_lm), B, S, C, st)
         return d_lm, d_am, None, None, None, None, None
@@ -204,10 +217,15 @@ class _SimpleLoss(torch.autograd.Function):
             _lib.call("ftr_simple_logprobs_bwd_w_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
                       _ptr(prod), _ptr(boundary), _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
             dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-            damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
-            _lib.call("ftr_simple_logprobs_bwd_am_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
-                      _ptr(damp), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
-                      modified, st)
+            if _use_fused_builder_bwd(C):                       # W^T lm_probs inside the d am kernel (opt-in)
+                _lib.call("ftr_simple_logprobs_fused_bwd_am_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
+                          _ptr(prod), _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am),
+                          B, T, S, C, modified, st)
+            else:
+                damp = torch.bmm(W.transpose(1, 2), lm_probs)   # [B,T,C]
+                _lib.call("ftr_simple_logprobs_bwd_am_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
+                          _ptr(damp), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
+                          modified, st)
             _lib.call("ftr_simple_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx), _ptr(rsy),
                       blank, _ptr(d_lm), B, S, C, st)
         return d_lm, d_am, None, None, None, None, None, None, None
@@ -767,10 +785,15 @@ def _smoothed_backward(saved, has_boundary, meta, gpx, gpy, scale=None, stride=0
         _lib.call("ftr_smoothed_logprobs_bwd_w_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
                   _ptr(boundary), cs, _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
         dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-        damp = torch.bmm(W.transpose(1, 2), lm_probs)       # [B,T,C]
-        _lib.call("ftr_smoothed_logprobs_bwd_am_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(damp),
-                  _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R),
-                  _ptr(d_am), B, T, S, C, modified, st)
+        if _use_fused_builder_bwd(C):                       # W^T lm_probs inside the d am kernel (opt-in)
+            _lib.call("ftr_smoothed_logprobs_fused_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
+                      _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs, cs + a_s, _ptr(u),
+                      _ptr(am_dot), a_s, _ptr(R), _ptr(d_am), B, T, S, C, modified, st)
+        else:
+            damp = torch.bmm(W.transpose(1, 2), lm_probs)   # [B,T,C]
+            _lib.call("ftr_smoothed_logprobs_bwd_am_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(damp),
+                      _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R),
+                      _ptr(d_am), B, T, S, C, modified, st)
         # d u: through amonly_norm and through ulog
         du = _colsum_weighted(am_probs, R, B * T, C, st)
         gul = torch.zeros((C,), dtype=torch.float32, device=dev)
