@@ -387,3 +387,78 @@ def test_absent_producer_poisons_loudly(ft, dev):
     stt, _ = _status(ft, dev, ws, B, S, T, lib=L)
     assert stt == 1
     assert torch.isnan(ans).all()
+
+
+def _band_case(ft, dev, B, T, S, r, modified, seed, offsets=False, break_end=False):
+    """Random band arrays on hand-built monotone ranges -> (band kernel results, lattice kernel results mapped to the band)."""
+    from tf_fast_rnnt import _lib
+    rng = np.random.default_rng(seed)
+    s0 = np.zeros((B, T), np.int64)
+    for b in range(B):
+        steps = rng.integers(0, max(r, 1), T)                          # 0 <= s0[t+1] - s0[t] <= r - 1
+        s0[b] = np.minimum(np.cumsum(steps) - steps[0], max(S + 1 - r, 0))
+        s0[b] = np.maximum.accumulate(s0[b])
+    if break_end:
+        s0[:, :] = 0                                                   # the band never reaches row S: no path (for S >= r)
+    ranges = (s0[:, :, None] + np.arange(r)[None, None, :]).astype(np.int32)
+    pxb = (-rng.random((B, T, r)) * 3 - 0.05).astype(np.float32)
+    pyb = (-rng.random((B, T, r)) * 3 - 0.05).astype(np.float32)
+    bd = np.zeros((B, 4), np.int32); bd[:, 2] = S; bd[:, 3] = T
+    if offsets:
+        for b in range(B):
+            tb = int(rng.integers(0, max(T // 3, 1))); te = int(rng.integers(max(tb + 1, (2 * T) // 3), T + 1))
+            lo, hi = int(s0[b, tb]), int(min(s0[b, te - 1] + r - 1, S))
+            sb = int(rng.integers(lo, min(lo + r, hi + 1))); se = int(rng.integers(max(sb, hi - r + 1), hi + 1))
+            bd[b] = (sb, tb, se, te)
+    T1 = T if modified else T + 1
+    px = np.full((B, S, T1), -np.inf, np.float32); py = np.full((B, S + 1, T), -np.inf, np.float32)
+    for b in range(B):
+        for t in range(T):
+            for k in range(r):
+                s = s0[b, t] + k
+                if s < S: px[b, s, t] = pxb[b, t, k]
+                if s <= S: py[b, s, t] = pyb[b, t, k]
+                if s >= S: pxb[b, t, k] = -np.inf                     # what the band builder writes there
+                if s > S: pyb[b, t, k] = -np.inf
+    if not modified:                                                   # fix_for_boundary (rnnt_loss.py:28-61): no symbol in column t_end
+        for b in range(B):
+            te = int(bd[b, 3])
+            if te < T: px[b, :, te] = -np.inf; pxb[b, te, :] = -np.inf
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tpx, tpy, tbd, trg = t_(pxb), t_(pyb), t_(bd), t_(ranges)
+    ans = torch.empty(B, device=dev); gxb = torch.empty_like(tpx); gyb = torch.empty_like(tpy)
+    st = torch.cuda.current_stream().cuda_stream
+    assert _lib.lib().ftr_mutual_information_band_supported(T, S, r) == 1
+    _lib.call("ftr_mutual_information_band_f32", tpx.data_ptr(), tpy.data_ptr(), trg.data_ptr(), tbd.data_ptr(), ans.data_ptr(),
+              gxb.data_ptr(), gyb.data_ptr(), B, T, S, r, int(modified), st)
+    lpx = t_(px).requires_grad_(True); lpy = t_(py).requires_grad_(True)
+    lans = ft.mutual_information_recursion(lpx, lpy, tbd)
+    fin = torch.isfinite(lans)
+    if fin.any(): lans[fin].sum().backward()
+    lgx = np.zeros_like(px) if lpx.grad is None else lpx.grad.cpu().numpy()
+    lgy = np.zeros_like(py) if lpy.grad is None else lpy.grad.cpu().numpy()
+    egx = np.zeros((B, T, r), np.float32); egy = np.zeros((B, T, r), np.float32)
+    for b in range(B):
+        for t in range(T):
+            for k in range(r):
+                s = s0[b, t] + k
+                if s < S and t < T1: egx[b, t, k] = lgx[b, s, t]
+                if s <= S: egy[b, t, k] = lgy[b, s, t]
+    return ans.cpu().numpy(), gxb.cpu().numpy(), gyb.cpu().numpy(), lans.detach().cpu().numpy(), egx, egy, fin.cpu().numpy()
+
+
+@pytest.mark.parametrize("modified", [False, True])
+@pytest.mark.parametrize("case", [dict(B=3, T=37, S=11, r=4, offsets=True), dict(B=2, T=1, S=0, r=1), dict(B=2, T=9, S=0, r=1),
+                                  dict(B=2, T=24, S=9, r=1), dict(B=2, T=50, S=30, r=16), dict(B=2, T=50, S=30, r=9, offsets=True),
+                                  dict(B=2, T=40, S=20, r=3, break_end=True), dict(B=2, T=6, S=40, r=8), dict(B=1, T=300, S=100, r=8, offsets=True)])
+def test_band_recursion_kernel_edge_cases(ft, dev, case, modified):
+    """ftr_mutual_information_band_f32 directly against the full-lattice kernels on the lattices the band expands to:
+    begin / end offsets inside the band, S = 0, T = 1, one-row bands, 16-lane chains (r > 8), bands that never reach the end
+    cell (ans = -inf on both routes, zero occupancies), lattices taller than long."""
+    a, gx, gy, la, egx, egy, fin = _band_case(ft, dev, modified=modified, seed=5, **case)
+    assert np.array_equal(np.isfinite(a), fin)
+    if fin.any():
+        np.testing.assert_allclose(a[fin], la[fin], rtol=1e-5, atol=1e-5)
+        assert np.abs(gx[fin] - egx[fin]).max() <= 2e-5 and np.abs(gy[fin] - egy[fin]).max() <= 2e-5
+    assert np.isfinite(gx).all() and np.isfinite(gy).all()
+    assert (gx[~fin] == 0).all() and (gy[~fin] == 0).all()

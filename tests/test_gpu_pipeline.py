@@ -551,7 +551,8 @@ def test_against_committed_golden_fixtures(ft, dev, name):
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
-@pytest.mark.parametrize("cfg", [(2, 70, 33, 12), (2, 129, 100, 20), (1, 200, 140, 16), (2, 65, 200, 8), (1, 63, 470, 24), (3, 64, 15, 36)])
+@pytest.mark.parametrize("cfg", [(2, 70, 33, 12), (2, 129, 100, 20), (1, 200, 140, 16), (2, 65, 200, 8), (1, 63, 470, 24), (3, 64, 15, 36),
+                                 (2, 1, 0, 4), (2, 5, 0, 8), (1, 3, 70, 4), (2, 64, 1, 4)])
 def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cfg, monkeypatch):
     """csrc/simple_fused.hip (f32-MFMA contraction + epilogue in one kernel) against the library-GEMM + epilogue route on
     shapes that hit every symbol-block count (4 / 7 / 10 / 13 per workgroup), several symbol tiles, ragged frame tiles,
@@ -608,3 +609,34 @@ def test_fused_d_am_kernel_matches_library_gemm_route(ft, dev, rnnt_type, cfg, m
     for f, l in zip(fused, library):
         assert np.isfinite(f).all()
         assert np.abs(f - l).max() <= 2e-5 * max(1.0, np.abs(l).max())
+
+
+@pytest.mark.parametrize("rows,C", [(1, 8), (63, 12), (64, 500), (65, 7), (1000, 33), (9632, 1024)])
+def test_batch_statistics_kernels(ft, dev, rows, C):
+    """ftr_colsum_weighted_f32 (two deterministic stages), ftr_rowdot_f32 and ftr_rowmax_exp_dot_f32 against float64 numpy:
+    slabs that do not divide the rows, vector and scalar column paths."""
+    from tf_fast_rnnt import _lib
+    rng = np.random.default_rng(rows + C)
+    x = rng.standard_normal((rows, C)).astype(np.float32)
+    w = rng.standard_normal(rows).astype(np.float32)
+    v = rng.random(C).astype(np.float32)
+    tx, tw, tv = _t(x, dev), _t(w, dev), _t(v, dev)
+    st = torch.cuda.current_stream().cuda_stream
+    n = _lib.lib().ftr_colsum_weighted_workspace_floats(rows, C)
+    ws = torch.empty(max(n, 1), device=dev); out = torch.empty(C, device=dev)
+    for _ in range(2):       # twice: bit-reproducible
+        _lib.call("ftr_colsum_weighted_f32", tx.data_ptr(), tw.data_ptr(), out.data_ptr(), ws.data_ptr(), n, rows, C, st)
+        got = out.cpu().numpy()
+        if _: assert np.array_equal(got, first)
+        first = got
+    want = (x.astype(np.float64) * w.astype(np.float64)[:, None]).sum(0)
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()) * max(1.0, np.sqrt(rows) / 8)
+    dot = torch.empty(rows, device=dev)
+    _lib.call("ftr_rowdot_f32", tx.data_ptr(), tv.data_ptr(), dot.data_ptr(), rows, C, st)
+    np.testing.assert_allclose(dot.cpu().numpy(), x.astype(np.float64) @ v.astype(np.float64), rtol=1e-4, atol=1e-4)
+    probs = torch.empty_like(tx); mx = torch.empty(rows, device=dev)
+    _lib.call("ftr_rowmax_exp_dot_f32", tx.data_ptr(), probs.data_ptr(), mx.data_ptr(), tv.data_ptr(), dot.data_ptr(), rows, C, st)
+    m = x.max(1); p = np.exp(x.astype(np.float64) - m[:, None])
+    np.testing.assert_allclose(mx.cpu().numpy(), m)
+    np.testing.assert_allclose(probs.cpu().numpy(), p, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(dot.cpu().numpy(), p @ v.astype(np.float64), rtol=1e-5)

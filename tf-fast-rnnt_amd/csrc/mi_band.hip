@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
   float2* O2 = reinterpret_cast<float2*>(cutSB + 16);               // 8-byte aligned: an even number of ints in front
   float* G = reinterpret_cast<float*>(O2 + ncap);
   float* cutA = G + ncap; float* cutB = cutA + 16; float* occ = cutB + 16;   // 16 each, indexed by s & 15
-  auto div_r = [&](int i) { return (int)__umulhi((unsigned)i, rinv); };   // i / r for 0 <= i < 2^32 / r
+  auto div_r = [&](int i) { return rinv ? (int)__umulhi((unsigned)i, rinv) : i; };   // i / r for 0 <= i < 2^32 / r (rinv = 0: r = 1)
 
   // ---- band start per lattice column: the column t_end has no frame of its own, it continues the last frame's band
   const int32_t* rg = ranges + (size_t)b * T * r;
@@ -441,7 +441,7 @@ int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int
   const int lanes = band_lanes(T, S, r);
   if (!lanes) { set_error("mutual_information_band: T=%d S=%d r=%d does not fit the LDS-resident kernel", T, S, r); return FTR_ERR_UNSUPPORTED; }
   if ((uint64_t)(T + 1) * r * r >= (1ull << 32)) { set_error("mutual_information_band: T * r too large"); return FTR_ERR_UNSUPPORTED; }
-  const unsigned rinv = (unsigned)(((1ull << 32) + r - 1) / r);   // i / r == umulhi(i, rinv) while i * (r - 1) < 2^32
+  const unsigned rinv = (r == 1) ? 0u : (unsigned)(((1ull << 32) + r - 1) / r);   // i / r == umulhi(i, rinv) while i * (r - 1) < 2^32; 0 stands for r = 1
   static bool big_ok = false;
   if (!big_ok) {   // 156 KB: the kernel also has a few bytes of static LDS (__syncthreads_or)
     const void* ks[4] = {reinterpret_cast<const void*>(mi_band_kernel<true, 8>), reinterpret_cast<const void*>(mi_band_kernel<false, 8>),
