@@ -345,15 +345,17 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
  * everything band shaped ([B,T,r]; row (b,t,k) <-> lattice cell (ranges[b,t,0] + k, t)):
  *   ftr_pruned_band_fwd_f32           lse [B,T,r] (rnnt_loss.py:942) and px_band / py_band = the values the full-size
  *                                     lattices would hold at the band cells (-inf rules and delay penalty included)
- *   ftr_mutual_information_band_f32   forward recursion, cut, backward recursion in ONE launch (one wave per utterance,
- *                                     LDS resident): ans [B] and the occupancies gx_band / gy_band (= px_grad / py_grad
- *                                     at the band cells, seed = ones)
+ *   ftr_mutual_information_band_f32   forward recursion, cut, backward recursion in ONE launch (one workgroup per
+ *                                     utterance, LDS resident): ans [B] and the occupancies gx_band / gy_band (= px_grad /
+ *                                     py_grad at the band cells, seed = ones)
  *   ftr_pruned_band_bwd_scaled_f32    d loss / d logits from the band-shaped occupancies (the _scaled semantics above)
- * PRECONDITION on `ranges` (what get_rnnt_prune_ranges produces; not checked on the device): for every utterance
- * ranges[b,t,0] is non-decreasing in t, grows by at most r - 1 per frame (at most 1 for the modified type), and
- * 0 <= ranges[b,t,0] <= S - r + 1.  Callers with arbitrary ranges use ftr_pruned_logprobs_* + the lattice recursion.
- * ftr_mutual_information_band_supported() says whether (T, S, r) fits the LDS-resident kernel (r <= 16 and about
- * 12 T r + 4 T bytes <= 150 KB); ftr_mutual_information_band_f32 returns FTR_ERR_UNSUPPORTED otherwise.
+ * PRECONDITION on `ranges` (what get_rnnt_prune_ranges produces): for every utterance ranges[b,t,0] is non-decreasing in
+ * t over the frames of the boundary rectangle.  ftr_mutual_information_band_f32 checks it on the device and answers a
+ * violation with ans[b] = NaN and zero occupancies; callers with arbitrary ranges use ftr_pruned_logprobs_* + the lattice
+ * recursion (the Python layer routes only ranges that come straight from get_rnnt_prune_ranges here).
+ * ftr_mutual_information_band_supported() says whether (T, S, r) fits the LDS-resident kernel: r <= 16 and
+ * 12 (S + T + 21) LANES + 4 (T + 34) bytes <= 150 KB with LANES = 8 (r <= 8) or 16; ftr_mutual_information_band_f32
+ * returns FTR_ERR_UNSUPPORTED otherwise.
  */
 int ftr_mutual_information_band_supported(int T, int S, int r);
 int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,

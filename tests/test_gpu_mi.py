@@ -462,3 +462,22 @@ def test_band_recursion_kernel_edge_cases(ft, dev, case, modified):
         assert np.abs(gx[fin] - egx[fin]).max() <= 2e-5 and np.abs(gy[fin] - egy[fin]).max() <= 2e-5
     assert np.isfinite(gx).all() and np.isfinite(gy).all()
     assert (gx[~fin] == 0).all() and (gy[~fin] == 0).all()
+
+
+def test_band_recursion_rejects_non_monotone_ranges(ft, dev):
+    """ranges[b,t,0] decreasing somewhere inside the rectangle: the band kernel answers NaN / zero occupancies instead of
+    computing on colliding slots (include/ftr.h, precondition of ftr_mutual_information_band_f32)."""
+    from tf_fast_rnnt import _lib
+    B, T, S, r = 2, 20, 8, 3
+    s0 = np.minimum(np.arange(T) // 3, S + 1 - r)
+    ranges = np.tile((s0[:, None] + np.arange(r)[None, :])[None], (B, 1, 1)).astype(np.int32)
+    ranges[1, 10] -= 1                                   # utterance 1: one step backwards
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pxb = t_(-np.ones((B, T, r), np.float32)); pyb = t_(-np.ones((B, T, r), np.float32))
+    bd = t_(np.array([[0, 0, S, T]] * B, np.int32))
+    ans = torch.empty(B, device=dev); gx = torch.full((B, T, r), 7.0, device=dev); gy = torch.full((B, T, r), 7.0, device=dev)
+    _lib.call("ftr_mutual_information_band_f32", pxb.data_ptr(), pyb.data_ptr(), t_(ranges).data_ptr(), bd.data_ptr(), ans.data_ptr(),
+              gx.data_ptr(), gy.data_ptr(), B, T, S, r, 0, torch.cuda.current_stream().cuda_stream)
+    a = ans.cpu().numpy()
+    assert np.isfinite(a[0]) and np.isnan(a[1])
+    assert (gx[1] == 0).all() and (gy[1] == 0).all() and float(gx[0].sum() + gy[0].sum()) > 0

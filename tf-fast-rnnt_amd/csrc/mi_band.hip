@@ -156,6 +156,17 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
   if (tid < 32) cutSA[tid] = -1;
   __syncthreads();
   FTR_BSTAMP(1);
+  {
+    // the one precondition the wavefront order rests on: the band start never decreases along t (two cells of one walk
+    // step would otherwise share a slot).  A violation is answered loudly: ans = NaN, zero occupancies.
+    int bad = 0;
+    for (int t = tb + 1 + tid; t < te; t += kBandThreads) bad |= (lo[t] < lo[t - 1]);
+    if (__syncthreads_or(bad)) {
+      for (size_t i = tid; i < cells_g; i += kBandThreads) { gx_g[i] = 0.0f; gy_g[i] = 0.0f; }
+      if (tid == 0) ans[b] = __builtin_nanf("");
+      return;
+    }
+  }
   if (tid < LANES) O2[(rowA + jm + 1) * LANES + tid] = make_float2(kNeg, 0.0f);   // chain A's pad step
   auto in_band = [&](int s, int t) { const int l = lo[t]; return s >= l && s <= l + r - 1; };
   // wavefront slot of a lattice cell in chain A's part / chain B's part of the arrays
