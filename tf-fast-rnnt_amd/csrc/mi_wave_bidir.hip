@@ -110,12 +110,14 @@ __device__ __forceinline__ bool comm_import(float* in_ring, u64* gran_in, int m,
     __builtin_amdgcn_s_sleep(FTR_POLL_SLEEP);
     g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (lane < CH) {
-    in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
-    // this band is the only reader: leave the granule zero for the next launch on this workspace (self-cleaning)
-    __hip_atomic_store(gran_in + idx, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (lane < CH) in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
   return true;
+}
+// this band is the only reader of its granules: it leaves them zero for the next launch on this workspace
+// (self-cleaning).  Issued AFTER the peek for the next chunk: in front of it, the next import's wait for that peek also
+// waits for these write-through stores (vmcnt is in order) -- 0.3 us per slot on every band that has a band above.
+__device__ __forceinline__ void comm_clear(u64* gran_in, int m, int lane) {
+  if (lane < CH) __hip_atomic_store(gran_in + CH * m + lane, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // values on the cut go to the last workgroup of the utterance (possibly on another XCD): write-through stores, read
 // back with agent-scope loads after the done[] counter says everybody has delivered
@@ -146,6 +148,7 @@ __device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
 #define FTR_TD(k) (lds + (6 + ((k) & 1)) * TILE_F4)
 #define FTR_TP(k) (lds + (8 + ((k) & 1)) * TILE_F4)
 constexpr int kFwdTiles = 10;
+constexpr int kFlowThreads = 320;   // flow kernel: compute, IO-in, COMM (loads only), IO-out px + hand-off stores, IO-out py
 constexpr int kAhead = 2;   // the IO-in wave parks chunk kc + kAhead during slot kc
 
 // ------------------------------------------------------------------------------------------------- forward
@@ -282,17 +285,17 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 
   if (wid == 2) {
     // ======================================================================= COMM wave
-    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;        // read (and cleared) by band w+1
     u64* gran_in = gran_b + (size_t)w * Tg;               // written by band w-1
-    // publish only what will be imported (and cleared): the band below returns at once when all its rows lie beyond
-    // the cut (its jl = jl - 64 * SKEW is negative); otherwise it imports exactly the chunks [0, klast) published here
-    const bool has_up = w > 0, has_down = (w + 1 < NWact) && (jl - 64 * SKEW >= 0);
+    // This wave issues LOADS only (peeks and poll reloads).  vmcnt retires in order, so a wave that both stores and polls
+    // waits, in front of every import, for its own write-through stores of the previous slot as well -- 0.2-0.3 us per
+    // slot on every band with a band above, more when the memory system is busy (profiles/r02_j).  The stores of the
+    // hand-off (publishing to the band below, clearing what was imported, the cut values) are the IO-out wave's.
+    const bool has_up = w > 0;
     bool dead = false;
     u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int m = kc + LOOK;
-      // import first: it waits for the peek issued one slot ago only, never for this slot's publishing stores
 #ifdef FTR_EXP_NOPOLL
       if (false) {
 #else
@@ -306,21 +309,6 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       // the next chunk's granules are requested now and looked at one whole slot later
       g_cur = 0;
       if (has_up && !dead && m + 1 >= 0 && m + 1 < klast_up) g_cur = comm_peek(gran_in, m + 1, lane);
-      if (kc - 1 >= 0 && kc - 1 < klast) {
-        const float* tp = reinterpret_cast<const float*>(FTR_TP(kc - 1));
-#ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
-        if (has_down && lane < CH && !(w == 0 && !REVM)) {
-#else
-        if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk kc-1 -> granules of the band below
-#endif
-          const int mm = kc - 1;
-          const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
-          const u64 g = ((u64)(unsigned)(mm + 1) << 32) | (u64)__float_as_uint(v);
-          __hip_atomic_store(gran_out + CH * mm + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (kc - 1 == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
-          pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
-      }
       FTR_SYNC();
     }
     FTR_SYNC_REPORT(2);
@@ -556,15 +544,40 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #endif
 
   if (wid == 3) {
-    // ------------------------------------------------------------------------- IO-out
+    // ------------------------------------------------------------------------- IO-out: G, and every store of the hand-off
+    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;        // read (and cleared) by band w+1
+    u64* gran_in = gran_b + (size_t)w * Tg;               // written by band w-1, imported by this band's COMM wave
+    // publish only what will be imported (and cleared): the band below returns at once when all its rows lie beyond
+    // the cut (its jl = jl - 64 * SKEW is negative); otherwise it imports exactly the chunks [0, klast) published here
+    const bool has_up = w > 0, has_down = (w + 1 < NWact) && (jl - 64 * SKEW >= 0);
+    auto clear_imported = [&](int mm) {   // what the COMM wave imported one slot ago: leave it zero for the next launch
+      if (has_up && mm >= 0 && mm < klast_up) comm_clear(gran_in, mm, lane);
+    };
     for (int gg = 0; gg < NIT * NPF; ++gg) {
-      const int k = base + gg - 1;          // the chunk the compute wave finished in the previous slot
+      const int kc = base + gg;
+      const int k = kc - 1;                 // the chunk the compute wave finished in the previous slot
+      if (k >= 0 && k < klast) {
+        const float* tp = reinterpret_cast<const float*>(FTR_TP(k));
+#ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
+        if (has_down && lane < CH && !(w == 0 && !REVM)) {
+#else
+        if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk k -> granules of the band below (first: latency critical)
+#endif
+          const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
+          const u64 g = ((u64)(unsigned)(k + 1) << 32) | (u64)__float_as_uint(v);
+          __hip_atomic_store(gran_out + CH * k + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (k == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
+          pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
+      }
+      clear_imported(kc - 1 + LOOK);
       if (k >= 0 && k < klast) {
         if (k >= K0 && k < K1) drain_fast(k);   // wave-uniform
         else drain_general(k);
       }
       FTR_SYNC();
     }
+    clear_imported(base + NIT * NPF - 1 + LOOK);
     FTR_SYNC_REPORT(3);
     return;
   }
@@ -1067,21 +1080,15 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 
   if (wid == 2) {
     // ======================================================================= COMM wave
-    // the import of the band above's flow (first: it only waits for the peek issued one slot ago and for stores that are
-    // a slot old), the request for the next chunk's granules, the hand-off to the band below (lane 63's xout of every
-    // step, read from the XO tile), the ans_grad self check and this band's py_grad stores (the IO-out wave keeps the
-    // px_grad stores: two balanced store streams).
-    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
+    // LOADS only, as in the forward kernel: the import of the band above's flow and the request for the next chunk's
+    // granules.  Every store of the hand-off is the IO-out wave's, the py_grad stores have a wave of their own (five waves
+    // per workgroup): a wave that polls must not have write-through stores of its own in flight, vmcnt retires in order.
     u64* gran_in = gran_b + (size_t)w * Tg;
-    const bool has_up = w > 0, has_down = w + 1 < NWact;
-    // publish only what the band below imports (and clears): its loop visits the chunks from
-    // max(kfirst_up, its kfirst - PRE + LOOK) on, with its jli = jli - 64 * SKEW
-    const int kpub = max(kfirst, max(jli - 64 * SKEW, 0) / CH - PRE + LOOK);
+    const bool has_up = w > 0;
     bool dead = false;
     u64 g_cur = 0;
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
-      const int k = kc - 1;
       const int m = kc + LOOK;
       if (has_up && !dead && m >= kfirst_up && m < nchunks) {
         if (!comm_import(in_ring, gran_in, m, lane, g_cur, status)) {
@@ -1092,6 +1099,26 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       // the next chunk's granules are requested now and looked at one whole slot later
       g_cur = 0;
       if (has_up && !dead && m + 1 >= kfirst_up && m + 1 < nchunks) g_cur = comm_peek(gran_in, m + 1, lane);
+      FTR_FSYNC();
+    }
+    FTR_FREPORT(2);
+    return;
+  }
+
+  if (wid == 3) {
+    // ------------------------------------------------------------------------- IO-out: px_grad and every store of the hand-off
+    // (to the band below: lane 63's xout of every step, read from the XO tile; clearing what the COMM wave imported one
+    // slot ago; the ans_grad self check)
+    u64* gran_out = gran_b + (size_t)(w + 1) * Tg;
+    u64* gran_in = gran_b + (size_t)w * Tg;
+    const bool has_up = w > 0, has_down = w + 1 < NWact;
+    // publish only what the band below imports (and clears): its loop visits the chunks from
+    // max(kfirst_up, its kfirst - PRE + LOOK) on, with its jli = jli - 64 * SKEW
+    const int kpub = max(kfirst, max(jli - 64 * SKEW, 0) / CH - PRE + LOOK);
+    auto clear_imported = [&](int mm) { if (has_up && mm >= kfirst_up && mm < nchunks) comm_clear(gran_in, mm, lane); };
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int kc = base + gg;
+      const int k = kc - 1;
       if (k >= kfirst && k < nchunks) {
         if (has_down && k >= kpub && lane < CH) {
           const float* txo = reinterpret_cast<const float*>(FTR_TXO(k));
@@ -1105,26 +1132,29 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           if (jfin == jli) pg += occ_b[REVM ? (Sn - 1 - (64 * w + lane)) : (64 * w + lane)] * (seed ? seed[b] : 1.0f);   // one-cell lattice
           check[b] = pg;
         }
-        if (k >= K0d && k < K1) drain_fast(k, std::false_type{}, std::true_type{});   // wave-uniform
-        else drain_general(k, std::false_type{}, std::true_type{});
       }
-      FTR_FSYNC();
-    }
-    FTR_FREPORT(2);
-    return;
-  }
-
-  if (wid == 3) {
-    // ------------------------------------------------------------------------- IO-out: px_grad
-    for (int gg = 0; gg < NIT * NPF; ++gg) {
-      const int k = base + gg - 1;
+      clear_imported(kc - 1 + LOOK);
       if (k >= kfirst && k < nchunks) {
         if (k >= K0d && k < K1) drain_fast(k, std::true_type{}, std::false_type{});   // wave-uniform
         else drain_general(k, std::true_type{}, std::false_type{});
       }
       FTR_FSYNC();
     }
+    clear_imported(base + NIT * NPF - 1 + LOOK);
     FTR_FREPORT(3);
+    return;
+  }
+
+  if (wid == 4) {
+    // ------------------------------------------------------------------------- IO-out: py_grad
+    for (int gg = 0; gg < NIT * NPF; ++gg) {
+      const int k = base + gg - 1;
+      if (k >= kfirst && k < nchunks) {
+        if (k >= K0d && k < K1) drain_fast(k, std::false_type{}, std::true_type{});   // wave-uniform
+        else drain_general(k, std::false_type{}, std::true_type{});
+      }
+      FTR_FSYNC();
+    }
     return;
   }
 
@@ -1184,7 +1214,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
 #undef FTR_TXO
 
 template <bool MOD>
-__global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
+__global__ __launch_bounds__(kFlowThreads) void mi_bidir_flow_kernel(
     const int32_t* __restrict__ boundary, const float* __restrict__ ws, u64* __restrict__ gran,
     const float* __restrict__ occ, float* __restrict__ px_grad, float* __restrict__ py_grad,
     const float* __restrict__ seed, float* __restrict__ check, int* __restrict__ ctrl, int B, int NB, int Tg, int S, int T) {
@@ -1209,8 +1239,8 @@ __global__ __launch_bounds__(256) void mi_bidir_flow_kernel(
   //      dir 0 workgroups fill px_grad, dir 1 workgroups fill py_grad.
   {
     const bool empty = (Sn <= 0 || Tn <= 0);
-    const int nwv = 4 * NB;                 // every band's four waves share the fill of this utterance
-    const int fwid = 4 * w + wid;
+    const int nwv = (kFlowThreads / 64) * NB;   // every band's waves share the fill of this utterance
+    const int fwid = (kFlowThreads / 64) * w + wid;
     if (dir == 0) {
       // px_grad is defined on rows [sb, se) x columns [tb, te - NOFF]
       const int xr0 = empty ? 0 : bd.sb, xr1 = empty ? 0 : bd.se;
@@ -1432,8 +1462,8 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(256), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
 }
 
