@@ -32,6 +32,7 @@ def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
     bd1 = torch.tensor([[0, 0, S1w, 64]], dtype=torch.int32, device=dev); ans1 = torch.empty(1, device=dev)
     gx1 = torch.empty_like(px1); gy1 = torch.empty_like(py1)
     nws1 = L.ftr_mutual_information_workspace_floats(1, S1w, 64); ws1 = torch.empty(nws1, dtype=torch.float32, device=dev)
+    dirty = torch.empty(int(os.environ.get("FTR_BENCH_DIRTY", "0")) * 1024 * 1024 // 4 + 1, device=dev)
     flags = int(os.environ.get("FTR_BENCH_FLAGS", "1"))   # 1 = FTR_MI_WS_CLEAN (what the package passes), 0 = memset per launch
     tf = tb = 0.0
     for i in range(iters + warm):
@@ -42,6 +43,10 @@ def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
             _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px1), _ptr(py1), _ptr(bd1), _ptr(ws1), nws1, 0, None, _ptr(gx1), _ptr(gy1), None, 0, 1, S1w, 64, 0, st)
         if cold and "ws" in pre: ws.copy_(ws)          # touch the whole workspace (read + write back)
         if cold and "in" in pre: px.copy_(px); py.copy_(py)
+        if os.environ.get("FTR_BENCH_FRESH_OUT"):      # outputs from the allocator every iteration, as inside a training step
+            gx = torch.empty_like(px); gy = torch.empty_like(py)
+        if os.environ.get("FTR_BENCH_DIRTY"):          # a writer of DIRTY MB in front of the pair (what the builder kernel leaves behind)
+            dirty.fill_(0.5)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
         if product:

@@ -15,5 +15,7 @@ L.ftr_debug_trace(buf, 1024)
 v = list(buf); t0 = v[0]; us = lambda x: (x - t0) / 100.0
 n = int(v[4]); ts = np.array([us(x) for x in v[16:16 + n]]); d = np.diff(ts)
 q = max(len(d) // 4, 1)
+if os.environ.get("FTR_TRACE_SLOTS"):
+    print("  slot end times (us):", " ".join(f"{t:.2f}" for t in ts))
 print(f"[{os.path.basename(os.environ.get('FTR_LIB_PATH', 'product'))}] fwd {f:.1f} us; kernel span {us(v[1]):.1f}; band alive {us(v[2]):.1f} .. {us(v[3]):.1f} us, {n} slots; "
       f"slot us: first quarter {d[:q].mean():.3f}, middle {d[q:3*q].mean():.3f}, last quarter {d[3*q:].mean():.3f}; max {d.max():.2f}; slots > 1.2 us: {(d > 1.2).sum()}")
