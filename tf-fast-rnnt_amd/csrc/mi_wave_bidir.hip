@@ -75,6 +75,13 @@ typedef unsigned long long u64;
 #define FTR_SYNC_DECL unsigned long long st_last = 0, st_busy = 0, st_wait = 0, st_n = 0; FTR_STAMP(st_last)
 #define FTR_SYNC() do { unsigned long long a_, b_; FTR_STAMP(a_); __syncthreads(); FTR_STAMP(b_); st_busy += a_ - st_last; st_wait += b_ - a_; st_last = b_; ++st_n; } while (0)
 #define FTR_SYNC_REPORT(slot) do { if (!REVM && b == 0 && w == FTR_STAMP_BAND && lane == 0) { g_stamps[4 * (slot)] = st_busy; g_stamps[4 * (slot) + 1] = st_wait; g_stamps[4 * (slot) + 2] = st_n; } } while (0)
+#elif defined(FTR_TRACE) && FTR_TRACE == 3
+// Diagnostic build: when does each wave of the traced forward band ARRIVE at the barrier of every slot?  g_trace[256 * wid +
+// 16 + n] for the waves' n-th barrier (n < 240), next to the start / end words of the FTR_TRACE == 1 layout
+// (scripts/mi_trace_waves.py).
+#define FTR_SYNC_DECL int tr_n = 0
+#define FTR_SYNC() do { if (b == 0 && REVM == (FTR_TRACE_DIR != 0) && w == FTR_STAMP_BAND && lane == 0 && tr_n < 240) g_trace[256 * wid + 16 + tr_n] = trace_now(); ++tr_n; __syncthreads(); } while (0)
+#define FTR_SYNC_REPORT(slot) do { if (b == 0 && REVM == (FTR_TRACE_DIR != 0) && w == FTR_STAMP_BAND && lane == 0 && (slot) == 1) g_trace[4] = tr_n; } while (0)
 #else
 #define FTR_SYNC_DECL do { } while (0)
 #define FTR_SYNC() __syncthreads()
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   const int b2 = blockIdx.x % (2 * B);
   const int w = blockIdx.x / (2 * B);            // band of 64 walk rows
   const int dir = b2 / B, b = b2 - dir * B;
-#if defined(FTR_TRACE) && FTR_TRACE == 1
+#if defined(FTR_TRACE) && (FTR_TRACE == 1 || FTR_TRACE == 3)
   if (threadIdx.x == 0) { const u64 t = trace_now(); atomicMin(&g_trace[0], t); if (b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[2] = t; }
 #endif
   const Bound bd = load_boundary(boundary, b, S, T);
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   // ---- the last of the 2 * NWact bands of this utterance to get here runs the cut reduction
   __builtin_amdgcn_s_waitcnt(kVmcnt0);           // this wave's cut values / flags have left
   __syncthreads();
-#if defined(FTR_TRACE) && FTR_TRACE == 1
+#if defined(FTR_TRACE) && (FTR_TRACE == 1 || FTR_TRACE == 3)
   if (threadIdx.x == 0) { const u64 t = trace_now(); atomicMax(&g_trace[1], t); if (b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[3] = t; }
 #endif
   int* sflag = reinterpret_cast<int*>(smem);
