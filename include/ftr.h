@@ -353,8 +353,8 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
  * t over the frames of the boundary rectangle.  ftr_mutual_information_band_f32 checks it on the device and answers a
  * violation with ans[b] = NaN and zero occupancies; callers with arbitrary ranges use ftr_pruned_logprobs_* + the lattice
  * recursion (the Python layer routes only ranges that come straight from get_rnnt_prune_ranges here).
- * ftr_mutual_information_band_supported() says whether (T, S, r) fits the LDS-resident kernel: r <= 16 and
- * 12 (S + T + 21) LANES + 4 (T + 34) bytes <= 150 KB with LANES = 8 (r <= 8) or 16; ftr_mutual_information_band_f32
+ * ftr_mutual_information_band_supported() says whether (T, S, r) fits the LDS-resident kernel: r <= 15 and
+ * 12 (S + T + 21) LANES + 4 (T + 34) bytes <= 150 KB with LANES = 8 (r <= 7) or 16; ftr_mutual_information_band_f32
  * returns FTR_ERR_UNSUPPORTED otherwise.
  */
 int ftr_mutual_information_band_supported(int T, int S, int r);

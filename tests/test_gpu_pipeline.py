@@ -464,7 +464,7 @@ def test_fused_smoothed_loss_matches_composed_path(ft, dev, reduction, rnnt_type
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
-@pytest.mark.parametrize("cfg", [(3, 40, 12, 20, 4), (2, 90, 33, 12, 5), (4, 64, 20, 16, 2), (2, 130, 50, 24, 8), (2, 70, 40, 8, 16),
+@pytest.mark.parametrize("cfg", [(3, 40, 12, 20, 4), (2, 90, 33, 12, 5), (4, 64, 20, 16, 2), (2, 130, 50, 24, 8), (2, 70, 40, 8, 16), (2, 70, 40, 8, 15), (2, 60, 30, 8, 7),
                                  (3, 33, 5, 7, 3), (2, 200, 50, 50, 5), (1, 300, 10, 16, 11), (2, 25, 20, 8, 6)])
 def test_band_native_pruned_loss_matches_lattice_path(ft, dev, oracle, rnnt_type, cfg):
     """rnnt_loss_pruned on the band itself (ftr_mutual_information_band_f32: ranges carrying get_rnnt_prune_ranges' mark)
@@ -640,3 +640,13 @@ def test_batch_statistics_kernels(ft, dev, rows, C):
     np.testing.assert_allclose(mx.cpu().numpy(), m)
     np.testing.assert_allclose(probs.cpu().numpy(), p, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(dot.cpu().numpy(), p @ v.astype(np.float64), rtol=1e-5)
+
+
+def test_pruned_loss_routes_fuzz(ft, dev):
+    """scripts/band_fuzz.py: 120 random pruned-loss problems (T from 1, one-row bands, r up to 20, both types, ragged
+    boundaries): the band-native route against the full-lattice route.  (Found the modified-type end cell that sits one row
+    above the last frame's band.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("band_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "band_fuzz.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    m.main(120, 20261004)

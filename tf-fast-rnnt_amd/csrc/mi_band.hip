@@ -26,7 +26,7 @@
 // the per-transition flows (= the occupancies px_grad / py_grad), which a last parallel phase stores band shaped.
 //
 // LDS (per utterance): lo[T+1] (band start per column) and three arrays of (S_n + T_n + 1) x LANES floats: OX, OY
-// (operands, later the two flow outputs) and G.  LANES = 8 while r <= 8, 16 up to r = 16.
+// (operands, later the two flow outputs) and G.  LANES = 8 while r <= 7, 16 up to r = 15 (r + 1 lanes: see in_band in the kernel).
 #include "ftr_common.h"
 #include <type_traits>
 
@@ -168,7 +168,12 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     }
   }
   if (tid < LANES) O2[(rowA + jm + 1) * LANES + tid] = make_float2(kNeg, 0.0f);   // chain A's pad step
-  auto in_band = [&](int s, int t) { const int l = lo[t]; return s >= l && s <= l + r - 1; };
+  // Column t_end has no frame: its cells are where the last frame's transitions lead.  For the regular type that is the
+  // last frame's band again (py moves along a row; px inside column t_end is masked by fix_for_boundary); for the modified
+  // type px moves up one row AND one column, so the END CELL may sit one row above that band (s_end = lo + r) and still be
+  // reached -- by the last frame's top px.  (Any other cell of column t_end is a dead end and needs no slot.)
+  const bool end_above = MOD && se == lo[te] + r;
+  auto in_band = [&](int s, int t) { const int l = lo[t]; return (s >= l && s <= l + r - 1) || (end_above && t == te && s == se); };
   // wavefront slot of a lattice cell in chain A's part / chain B's part of the arrays
   auto slotA = [&](int s, int t) { return (rowA + (MOD ? (t - tb) : (s - sb) + (t - tb))) * LANES + ((s - sb) & (LANES - 1)); };
   auto slotB = [&](int s, int t) { return (rowB + (MOD ? (te - t) : (se - s) + (te - t))) * LANES + ((se - s) & (LANES - 1)); };
@@ -226,6 +231,9 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
         if (ISX && dg == jm) cutSB[(se - s) & (LANES - 1)] = s;
       }
     }
+    // the end cell outside the band of column t_end (see in_band): chain B's origin, no outgoing transitions; its walk
+    // step D is behind the cut unless the rectangle is a single column (handled above)
+    if (end_above && tid == 0) O[2 * slotB(se, te)] = ISX ? kNeg : 0.0f;
   };
   stage(pxb);
   __syncthreads();
@@ -427,11 +435,13 @@ __global__ void band_grad_banded_kernel(const float* __restrict__ logits, const 
 
 }  // namespace
 
-// 8-lane chains while the band is at most 8 rows wide (half the LDS), 16-lane chains up to 16 rows
+// 8-lane chains while the band is at most 7 rows wide (half the LDS), 16-lane chains up to 15 rows
 static int band_lanes(int T, int S, int r) {
   if (r < 1 || T < 1 || S < 0) return 0;
-  if (r <= 8 && band_lds_bytes<8>(T, S) <= (size_t)150 * 1024) return 8;
-  if (r <= 16 && band_lds_bytes<16>(T, S) <= (size_t)150 * 1024) return 16;
+  // r + 1 lanes: the modified type may have r + 1 cells on its last walk step (the end cell one row above the last
+  // frame's band, see the kernel)
+  if (r <= 7 && band_lds_bytes<8>(T, S) <= (size_t)150 * 1024) return 8;
+  if (r <= 15 && band_lds_bytes<16>(T, S) <= (size_t)150 * 1024) return 16;
   return 0;
 }
 int mi_band_supported(int T, int S, int r) { return band_lanes(T, S, r) != 0 ? 1 : 0; }
