@@ -650,3 +650,13 @@ def test_pruned_loss_routes_fuzz(ft, dev):
     spec = importlib.util.spec_from_file_location("band_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "band_fuzz.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     m.main(120, 20261004)
+
+
+def test_fused_builder_kernels_fuzz(ft, dev):
+    """scripts/builder_fuzz.py: 80 random builder problems (S from 0, T from 1, C = 4..316, both types, boundaries, penalty):
+    the fused forward and the opt-in fused d am kernel against the library-GEMM route -- log-probs of the simple and smoothed
+    builders and the gradients of both losses, 1e-4 normwise (the contractions sum in different orders)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("builder_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "builder_fuzz.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    m.main(80, 20261004)
