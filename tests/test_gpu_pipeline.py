@@ -660,3 +660,40 @@ def test_fused_builder_kernels_fuzz(ft, dev):
     spec = importlib.util.spec_from_file_location("builder_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "builder_fuzz.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     m.main(80, 20261004)
+
+
+def test_prune_ranges_fuzz_bit_exact(ft, dev, oracle):
+    """scripts/prune_fuzz.py: 120 random inputs (ties, ragged boundaries, window lengths 1 .. S+3 incl. the > 16 generic
+    kernel, both types): ranges bit for bit against the oracle."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("prune_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "prune_fuzz.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    m.main(120, 20261004)
+
+
+def test_whole_pipeline_fuzz_against_oracle(ft, dev, oracle):
+    """40 random small problems through the whole package path (simple loss with occupancies -> ranges -> gather -> pruned
+    loss + gradient) against the float64 oracle fed with the SAME ranges: loss 1e-4, gradient 2e-4 normwise; regular and
+    modified, ragged boundaries, r from 1."""
+    rng = np.random.default_rng(77)
+    for it in range(40):
+        B = int(rng.integers(1, 4)); T = int(rng.choice([3, 8, 17, 40])); S = int(rng.choice([1, 2, 5, 12])); C = int(rng.choice([4, 5, 8, 10]))
+        r = int(rng.choice([1, 2, 3, 5, 8])); rt = "modified" if rng.integers(0, 2) else "regular"
+        if rt == "modified" and S > T: S = T
+        d = synthetic(int(rng.integers(1, 10**6)), B, T, S, C, ragged=bool(rng.integers(0, 2)))
+        blank = d["termination_symbol"]
+        am, lm, sym, bd = (_t(d[k], dev) for k in ("am", "lm", "symbols", "boundary"))
+        _, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, rt, reduction="sum", calc_gradients=True)
+        ranges = ft.get_rnnt_prune_ranges(gx, gy, bd, r)
+        am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
+        logits = torch.tanh(am_p + lm_p).detach().requires_grad_(True)
+        loss = ft.rnnt_loss_pruned(logits, sym, ranges, blank, bd, rt, 0.05, "none")
+        fin = torch.isfinite(loss)
+        if fin.any(): loss[fin].sum().backward()
+        o_loss, o_g = oracle.rnnt_loss_pruned_grad(logits.detach().cpu().numpy(), d["symbols"], ranges.cpu().numpy(), blank, d["boundary"],
+                                                   rnnt_type=rt, delay_penalty=0.05, reduction="none", dtype=np.float64)
+        f = fin.cpu().numpy()
+        assert np.array_equal(f, np.isfinite(o_loss)), (it, B, T, S, C, r, rt)
+        if f.any():
+            np.testing.assert_allclose(loss.detach().cpu().numpy()[f], o_loss[f], rtol=1e-4, atol=1e-5)
+            assert max_rel(logits.grad.cpu().numpy()[f], o_g[f]) <= 2e-4, (it, B, T, S, C, r, rt)
