@@ -143,6 +143,7 @@ CALL_KERNELS = {
     "ftr_pruned_logprobs_fwd_f32": ["lse_rows_kernel<true>", "band_to_lattice_kernel<false>"],
     "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_gather_kernel<false>"],
     "ftr_mutual_information_band_f32": ["mi_band_kernel<false, 8>"],
+    "ftr_mutual_information_band_ws_f32": ["mi_band_kernel<false, 8>"],
     "ftr_pruned_band_bwd_scaled_f32": ["band_grad_banded_kernel<true>"],
     "ftr_pruned_logprobs_bwd_f32": ["band_grad_kernel<false, true>"],
     "ftr_pruned_logprobs_bwd_scaled_f32": ["band_grad_kernel<false, true>"],
@@ -218,6 +219,7 @@ def algorithmic_bytes(B, T, S, C, r):
         # the band path of rnnt_loss_pruned (3 N + O(B T r) for the pruned loss with a banded DP)
         "ftr_pruned_band_fwd_f32": N + 4 * 3 * B * T * r,                # stream logits once; lse, px_band, py_band
         "ftr_mutual_information_band_f32": 4 * 5 * B * T * r,            # band in, occupancies out (lives in LDS in between)
+        "ftr_mutual_information_band_ws_f32": 4 * 5 * B * T * r,
         "ftr_pruned_band_bwd_scaled_f32": 2 * N + 4 * 3 * B * T * r,     # re-read logits, write the gradient
         "ftr_pruned_logprobs_bwd_f32": 2 * N + 4 * (npx + npy),          # re-read logits, write the gradient
     }

@@ -353,11 +353,18 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
  * t over the frames of the boundary rectangle.  ftr_mutual_information_band_f32 checks it on the device and answers a
  * violation with ans[b] = NaN and zero occupancies; callers with arbitrary ranges use ftr_pruned_logprobs_* + the lattice
  * recursion (the Python layer routes only ranges that come straight from get_rnnt_prune_ranges here).
- * ftr_mutual_information_band_supported() says whether (T, S, r) fits the LDS-resident kernel: r <= 15 and
- * 12 (S + T + 21) LANES + 4 (T + 34) bytes <= 150 KB with LANES = 8 (r <= 7) or 16; ftr_mutual_information_band_f32
- * returns FTR_ERR_UNSUPPORTED otherwise.
+ * ftr_mutual_information_band_supported(T, S, r): 1 = the LDS-resident kernel (r <= 15 and 12 (S + T + 21) LANES +
+ * 4 (T + 34) bytes <= 150 KB with LANES = 8 for r <= 7, else 16); 2 = the streaming kernel for longer utterances, which
+ * keeps its wavefront-ordered arrays in a caller-provided workspace of ftr_mutual_information_band_workspace_floats()
+ * floats (16-byte aligned; contents need not survive the call) -- pass it to ftr_mutual_information_band_ws_f32;
+ * 0 = outside both (r > 15).  ftr_mutual_information_band_f32 is the _ws form without a workspace (kind 1 only).
  */
 int ftr_mutual_information_band_supported(int T, int S, int r);
+size_t ftr_mutual_information_band_workspace_floats(int B, int T, int S, int r);
+int ftr_mutual_information_band_ws_f32(const float* px_band, const float* py_band, const int32_t* ranges,
+                                       const int32_t* boundary, float* workspace, size_t workspace_floats, float* ans,
+                                       float* gx_band, float* gy_band, int B, int T, int S, int r, int modified,
+                                       void* stream);
 int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
                             int termination_symbol, double delay_penalty, float* lse, float* px_band, float* py_band,
                             int B, int T, int S, int C, int r, int modified, void* stream);

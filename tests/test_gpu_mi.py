@@ -428,9 +428,11 @@ def _band_case(ft, dev, B, T, S, r, modified, seed, offsets=False, break_end=Fal
     tpx, tpy, tbd, trg = t_(pxb), t_(pyb), t_(bd), t_(ranges)
     ans = torch.empty(B, device=dev); gxb = torch.empty_like(tpx); gyb = torch.empty_like(tpy)
     st = torch.cuda.current_stream().cuda_stream
-    assert _lib.lib().ftr_mutual_information_band_supported(T, S, r) == 1
-    _lib.call("ftr_mutual_information_band_f32", tpx.data_ptr(), tpy.data_ptr(), trg.data_ptr(), tbd.data_ptr(), ans.data_ptr(),
-              gxb.data_ptr(), gyb.data_ptr(), B, T, S, r, int(modified), st)
+    assert _lib.lib().ftr_mutual_information_band_supported(T, S, r) in (1, 2)    # 2: the streaming kernel (long utterances)
+    nws = _lib.lib().ftr_mutual_information_band_workspace_floats(B, T, S, r)
+    bws = torch.empty(max(nws, 1), device=dev)
+    _lib.call("ftr_mutual_information_band_ws_f32", tpx.data_ptr(), tpy.data_ptr(), trg.data_ptr(), tbd.data_ptr(), bws.data_ptr(), nws,
+              ans.data_ptr(), gxb.data_ptr(), gyb.data_ptr(), B, T, S, r, int(modified), st)
     lpx = t_(px).requires_grad_(True); lpy = t_(py).requires_grad_(True)
     lans = ft.mutual_information_recursion(lpx, lpy, tbd)
     fin = torch.isfinite(lans)
@@ -450,16 +452,19 @@ def _band_case(ft, dev, B, T, S, r, modified, seed, offsets=False, break_end=Fal
 @pytest.mark.parametrize("modified", [False, True])
 @pytest.mark.parametrize("case", [dict(B=3, T=37, S=11, r=4, offsets=True), dict(B=2, T=1, S=0, r=1), dict(B=2, T=9, S=0, r=1),
                                   dict(B=2, T=24, S=9, r=1), dict(B=2, T=50, S=30, r=15), dict(B=2, T=50, S=30, r=9, offsets=True),
-                                  dict(B=2, T=40, S=20, r=3, break_end=True), dict(B=2, T=6, S=40, r=8), dict(B=1, T=300, S=100, r=8, offsets=True)])
+                                  dict(B=2, T=40, S=20, r=3, break_end=True), dict(B=2, T=6, S=40, r=8), dict(B=1, T=300, S=100, r=8, offsets=True),
+                                  dict(B=2, T=2200, S=500, r=5), dict(B=1, T=1500, S=700, r=10, offsets=True)])
 def test_band_recursion_kernel_edge_cases(ft, dev, case, modified):
     """ftr_mutual_information_band_f32 directly against the full-lattice kernels on the lattices the band expands to:
     begin / end offsets inside the band, S = 0, T = 1, one-row bands, 16-lane chains (r > 8), bands that never reach the end
-    cell (ans = -inf on both routes, zero occupancies), lattices taller than long."""
+    cell (ans = -inf on both routes, zero occupancies), lattices taller than long; the last two are too long for LDS and
+    run through the streaming kernel (workspace in global memory)."""
     a, gx, gy, la, egx, egy, fin = _band_case(ft, dev, modified=modified, seed=5, **case)
     assert np.array_equal(np.isfinite(a), fin)
     if fin.any():
         np.testing.assert_allclose(a[fin], la[fin], rtol=1e-5, atol=1e-5)
-        assert np.abs(gx[fin] - egx[fin]).max() <= 2e-5 and np.abs(gy[fin] - egy[fin]).max() <= 2e-5
+        tol = 2e-5 if case["T"] <= 500 else 1e-4      # two float32 evaluations; the long cases accumulate more rounding
+        assert np.abs(gx[fin] - egx[fin]).max() <= tol and np.abs(gy[fin] - egy[fin]).max() <= tol
     assert np.isfinite(gx).all() and np.isfinite(gy).all()
     assert (gx[~fin] == 0).all() and (gy[~fin] == 0).all()
 

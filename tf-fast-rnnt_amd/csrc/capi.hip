@@ -50,7 +50,7 @@ using namespace ftr;
 
 extern "C" {
 
-int ftr_abi_version(void) { return 110; }
+int ftr_abi_version(void) { return 120; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
@@ -599,13 +599,24 @@ int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const i
 int ftr_mutual_information_band_f32(const float* px_band, const float* py_band, const int32_t* ranges,
                                     const int32_t* boundary, float* ans, float* gx_band, float* gy_band, int B, int T,
                                     int S, int r, int modified, void* stream) {
+  return ftr_mutual_information_band_ws_f32(px_band, py_band, ranges, boundary, nullptr, 0, ans, gx_band, gy_band, B, T, S, r, modified, stream);
+}
+
+size_t ftr_mutual_information_band_workspace_floats(int B, int T, int S, int r) {
+  return (B < 0 || T < 1 || S < 0 || r < 1) ? 0 : mi_band_workspace_floats(B, T, S, r);
+}
+
+int ftr_mutual_information_band_ws_f32(const float* px_band, const float* py_band, const int32_t* ranges,
+                                       const int32_t* boundary, float* workspace, size_t workspace_floats, float* ans,
+                                       float* gx_band, float* gy_band, int B, int T, int S, int r, int modified,
+                                       void* stream) {
   clear_error();
   FTR_REQUIRE(B >= 0 && T >= 1 && S >= 0 && r >= 1, "mutual_information_band: bad sizes");
   if (B == 0) return FTR_OK;
   FTR_REQUIRE(px_band && py_band && ranges && ans && gx_band && gy_band, "mutual_information_band: null pointer");
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
-  return mi_band(px_band, py_band, ranges, boundary, ans, gx_band, gy_band, B, T, S, r, modified, reinterpret_cast<hipStream_t>(stream));
+  return mi_band(px_band, py_band, ranges, boundary, workspace, workspace_floats, ans, gx_band, gy_band, B, T, S, r, modified, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_pruned_band_bwd_scaled_f32(const float* logits, const int32_t* symbols, const int32_t* ranges,

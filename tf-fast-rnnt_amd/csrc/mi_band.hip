@@ -29,6 +29,7 @@
 // (operands, later the two flow outputs) and G.  LANES = 8 while r <= 7, 16 up to r = 15 (r + 1 lanes: see in_band in the kernel).
 #include "ftr_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace ftr {
 namespace {
@@ -376,6 +377,231 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
   FTR_BSTAMP(9);
 }
 
+// ---------------------------------------------------------------------------------------- the band recursion, streaming
+// The same algorithm for bands that do not fit LDS (long utterances: (S + T) LANES 12 bytes > 150 KB): the wavefront-ordered
+// operand / ratio / flow arrays live in a global-memory workspace (a few hundred KB per utterance, L2 resident) and the two
+// chains stream through them -- consecutive addresses, fetched kStreamSets - 1 groups of four steps (44 steps, ~1.7 us) ahead
+// of their use, which hides the global latency the way two groups hide the LDS latency above.  Only lo[] (the band start per
+// column) and the cut exchange stay in LDS.  Differences to the LDS kernel, all for the sake of a predicate-free loop with one
+// fixed trip count for both chains: every slot is pre-filled with (OX, OY) = (-inf, 0) and G = 0 -- a step on such a slot
+// leaves the lane's value unchanged and passes no flow -- and each part is followed by 2 P pad rows (P = 48 steps), so the
+// loops simply run P-step blocks past their ends; the band inputs are read straight from global memory by the scatter pass.
+constexpr int kStreamSets = 12;                               // register sets of kBandAhead steps each
+constexpr int kStreamP = kStreamSets * kBandAhead;            // 48: block of steps per loop iteration
+template <int LANES>
+__host__ __device__ inline size_t band_stream_rows(int T, int S) { return (size_t)S + T + 4 + 6 * kStreamP; }
+template <int LANES>
+__host__ __device__ inline size_t band_stream_floats_per_utt(int T, int S) { return 3 * band_stream_rows<LANES>(T, S) * LANES; }
+inline size_t band_stream_lds_bytes(int T) { return sizeof(int) * ((size_t)(T + 2) + 32) + sizeof(float) * 48 + 64; }
+
+template <bool MOD, int LANES>
+__global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
+    const float* __restrict__ pxb, const float* __restrict__ pyb, const int32_t* __restrict__ ranges,
+    const int32_t* __restrict__ boundary, float* __restrict__ ws, float* __restrict__ ans, float* __restrict__ gxb,
+    float* __restrict__ gyb, int B, int T, int S, int r, unsigned rinv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Bound bd = load_boundary(boundary, b, S, T);
+  const int Sn = bd.se - bd.sb + 1, Tn = bd.te - bd.tb + 1;
+  const size_t cells_g = (size_t)T * r;
+  float* gx_g = gxb + (size_t)b * cells_g;
+  float* gy_g = gyb + (size_t)b * cells_g;
+  if (Sn <= 0 || Tn <= 0 || Tn == 1) {
+    for (size_t i = tid; i < cells_g; i += kBandThreads) { gx_g[i] = 0.0f; gy_g[i] = 0.0f; }
+    if (tid == 0) ans[b] = (Sn <= 0 || Tn <= 0) ? 0.0f : ((Sn == 1) ? 0.0f : -INFINITY);
+    return;
+  }
+  const int te = bd.te, tb = bd.tb, sb = bd.sb, se = bd.se;
+  const int D = (MOD ? 0 : (Sn - 1)) + (Tn - 1);
+  const int jm = D >> 1;
+  constexpr int P = kStreamP;
+  const int rowA = 2 * P, rowB = rowA + (jm + 1) + 2 * P;          // [2P pad][A part][2P pad][B part][2P pad]
+  const int nrows = rowB + (D - jm + 1) + 2 * P;
+  // ---- LDS: lo[], cut rows, cut exchange;  global: O2 (float2 per slot), G
+  int* lo = reinterpret_cast<int*>(smem);
+  int* cutSA = lo + ((T + 2) & ~1); int* cutSB = cutSA + 16;
+  float* cutA = reinterpret_cast<float*>(cutSB + 16); float* cutB = cutA + 16; float* occ = cutB + 16;
+  float* wsb = ws + (size_t)b * band_stream_floats_per_utt<LANES>(T, S);
+  float2* O2 = reinterpret_cast<float2*>(wsb);
+  float* G = wsb + 2 * band_stream_rows<LANES>(T, S) * LANES;
+  auto div_r = [&](int i) { return rinv ? (int)__umulhi((unsigned)i, rinv) : i; };
+
+  const int32_t* rg = ranges + (size_t)b * T * r;
+  for (int t0 = 0; t0 <= T; t0 += 4 * kBandThreads) {
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int t = t0 + u * kBandThreads + tid; v[u] = (t <= T) ? rg[(size_t)min(t, te - 1) * r] : 0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int t = t0 + u * kBandThreads + tid; if (t <= T) lo[t] = v[u]; }
+  }
+  for (int i = tid; i < nrows * LANES; i += kBandThreads) { O2[i] = make_float2(kNeg, 0.0f); G[i] = 0.0f; }   // neutral slots
+  if (tid < 32) cutSA[tid] = -1;
+  __syncthreads();
+  {
+    int bad = 0;
+    for (int t = tb + 1 + tid; t < te; t += kBandThreads) bad |= (lo[t] < lo[t - 1]);
+    if (__syncthreads_or(bad)) {     // see the LDS kernel: the band start must not decrease
+      for (size_t i = tid; i < cells_g; i += kBandThreads) { gx_g[i] = 0.0f; gy_g[i] = 0.0f; }
+      if (tid == 0) ans[b] = __builtin_nanf("");
+      return;
+    }
+  }
+  const bool end_above = MOD && se == lo[te] + r;              // see the LDS kernel
+  auto in_band = [&](int s, int t) { const int l = lo[t]; return (s >= l && s <= l + r - 1) || (end_above && t == te && s == se); };
+  auto slotA = [&](int s, int t) { return (rowA + (MOD ? (t - tb) : (s - sb) + (t - tb))) * LANES + ((s - sb) & (LANES - 1)); };
+  auto slotB = [&](int s, int t) { return (rowB + (MOD ? (te - t) : (se - s) + (te - t))) * LANES + ((se - s) & (LANES - 1)); };
+  // band value at lattice cell (s, t), frame t < te, log2 domain
+  const float* pxu = pxb + (size_t)b * T * r;
+  const float* pyu = pyb + (size_t)b * T * r;
+  auto at = [&](const float* src, int s, int t) { return src[(size_t)t * r + (s - lo[t])] * kLog2e; };
+  unsigned nan_acc = 0;
+  auto put = [&](int slot, float x, float y) {
+    nan_acc = max(nan_acc, max(__float_as_uint(x) & 0x7fffffffu, __float_as_uint(y) & 0x7fffffffu));
+    O2[slot] = make_float2(fmaxf(x, kNeg), fmaxf(y, kNeg));
+  };
+  // ---- operands of every band cell, both arrays in one pass, straight from global memory
+  for (int i = tid; i < Tn * r; i += kBandThreads) {
+    const int q = div_r(i);
+    const int t = tb + q, k = i - q * r;
+    const int s = lo[t] + k;
+    if (s < sb || s > se) continue;
+    const int dg = MOD ? (t - tb) : (s - sb) + (t - tb);
+    if (dg <= jm) {        // chain A: the transitions INTO the cell
+      float ax = kNeg, ay = kNeg;
+      const int tx = MOD ? t - 1 : t;
+      if (s - 1 >= sb && tx >= tb && tx <= te - 1 && in_band(s - 1, tx)) ax = at(pxu, s - 1, tx);
+      if (t - 1 >= tb && in_band(s, t - 1)) ay = at(pyu, s, t - 1);
+      if (s == sb && t == tb) ay = 0.0f;                               // origin trick
+      put(slotA(s, t), ax, ay);
+      if (dg == jm) cutSA[(s - sb) & (LANES - 1)] = s;
+    }
+    if (dg >= jm) {        // chain B: the transitions OUT of the cell
+      float bx = kNeg, by = kNeg;
+      if (t <= te - 1) {
+        const int tnx = MOD ? t + 1 : t;
+        if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) bx = at(pxu, s, t);
+        if (in_band(s, t + 1)) by = at(pyu, s, t);
+      }
+      if (s == se && t == te) by = 0.0f;                               // chain B's origin is the end cell
+      put(slotB(s, t), bx, by);
+      if (dg == jm) cutSB[(se - s) & (LANES - 1)] = s;
+    }
+  }
+  if (end_above && tid == 0) O2[slotB(se, te)] = make_float2(kNeg, 0.0f);
+  const bool poisoned = __syncthreads_or(nan_acc > 0x7f800000u) != 0;
+  __threadfence();   // the slots were written by other waves of this workgroup: nothing stale in this CU's L1 from here on
+
+  if (wave == 0) {
+    constexpr int U = kBandAhead, NS = kStreamSets;
+    const int l16 = lane & 15;
+    const int lg = l16 & (LANES - 1);
+    const bool isB = ((lane >> 4) & 1) == 1;
+    float val = (lg == 0) ? 0.0f : kNeg;
+    const int n1 = D - jm + 1;
+    const int nrun = ((n1 + P - 1) / P) * P;                    // both chains, whole blocks: the surplus steps are neutral
+    const int base1 = (isB ? rowB : rowA) * LANES + lg;
+    auto fwd = [&](int slot, float2 o) {
+      const float up = dpp_row_ror1(val);
+      const float a_ = up + o.x, b_ = val + o.y;
+      const float d = a_ - b_;
+      const float ex = __builtin_amdgcn_exp2f(-__builtin_fabsf(d));
+      val = fmaxf(a_, b_) + __builtin_amdgcn_logf(1.0f + ex);
+      const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+      G[slot] = (d >= 0.0f) ? rc : ex * rc;
+    };
+    {
+      float2 o[NS][U];
+#pragma unroll
+      for (int k = 0; k < NS - 1; ++k)
+#pragma unroll
+        for (int u = 0; u < U; ++u) o[k][u] = O2[base1 + (k * U + u) * LANES];
+      for (int i = 0; i < nrun; i += P) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int kf = (k + NS - 1) % NS;                     // the set NS - 1 groups ahead
+#pragma unroll
+          for (int u = 0; u < U; ++u) o[kf][u] = O2[base1 + (i + (k + NS - 1) * U + u) * LANES];
+#pragma unroll
+          for (int u = 0; u < U; ++u) fwd(base1 + (i + k * U + u) * LANES, o[k][u]);
+        }
+      }
+    }
+    // ---- the cut (LDS), as in the LDS kernel
+    if (lane < 48) cutA[lane] = kNeg;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int scut = (isB ? cutSB : cutSA)[lg];
+    if (scut >= 0) (isB ? cutB : cutA)[scut & 15] = val;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const float v = cutA[l16] + cutB[l16];
+      const float m = row16_max(v);
+      const float e = exp2f(v - m);
+      const float sum = row16_sum(e);
+      const float total = m + log2f(sum);
+      const bool dead = !(total > kNegThresh);
+      if (lane < 16) occ[lane] = (dead || poisoned) ? 0.0f : e / sum;
+      if (lane == 0) ans[b] = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : total * kLn2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float inj = (scut >= 0) ? occ[scut & 15] : 0.0f;
+    __builtin_amdgcn_s_waitcnt(0);                              // the ratios of both chains are in memory before anybody reads them
+    // ---- flow: each chain walks down through the other chain's part (and on into the neutral pad rows)
+    float xo = 0.0f, yo = 0.0f;
+    const int n2 = D - jm + 1;
+    const int nrun2 = ((n2 - 1 + P - 1) / P) * P;               // steps after the first one, whole blocks
+    const int top = (isB ? rowA + jm : rowB + D - jm) * LANES + ((Sn - 1 - lg) & (LANES - 1));
+    auto flow = [&](int slot, float g, auto first) {
+      const float xin = dpp_row_ror1(xo), yin = yo;
+      float pg = xin + yin;
+      if (decltype(first)::value) pg += inj;
+      O2[slot] = make_float2(xin, yin);
+      xo = pg * g; yo = pg - xo;
+    };
+    flow(top, G[top], std::true_type{});
+    {
+      float g[NS][U];
+#pragma unroll
+      for (int k = 0; k < NS - 1; ++k)
+#pragma unroll
+        for (int u = 0; u < U; ++u) g[k][u] = G[top - (1 + k * U + u) * LANES];
+      for (int i = 1; i < 1 + nrun2; i += P) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int kf = (k + NS - 1) % NS;
+#pragma unroll
+          for (int u = 0; u < U; ++u) g[kf][u] = G[top - (i + (k + NS - 1) * U + u) * LANES];
+#pragma unroll
+          for (int u = 0; u < U; ++u) flow(top - (i + k * U + u) * LANES, g[k][u], std::false_type{});
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+  }   // wave 0
+  __syncthreads();
+  __threadfence();   // wave 0's flows, read by everybody (this CU's L1 may hold the operand values of the same slots)
+  for (int i = tid; i < T * r; i += kBandThreads) {
+    const int t = div_r(i), k = i - t * r;
+    float fx = 0.0f, fy = 0.0f;
+    if (t >= tb && t < te) {
+      const int s = lo[t] + k;
+      if (s >= sb && s <= se) {
+        const int dg = MOD ? (t - tb) : (s - sb) + (t - tb);
+        if (dg < jm) { const float2 f = O2[slotA(s, t)]; fx = f.x; fy = f.y; }
+        else {
+          const int tnx = MOD ? t + 1 : t;
+          if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) fx = O2[slotB(s + 1, tnx)].x;
+          if (in_band(s, t + 1)) fy = O2[slotB(s, t + 1)].y;
+        }
+      }
+    }
+    gx_g[i] = fx;
+    gy_g[i] = fy;
+  }
+}
+
 // ---------------------------------------------------------------------------------------- gradient w.r.t. logits
 // the band_grad_kernel of pruned_logprobs.hip with the occupancies read band shaped (row = (b,t,k)); one wave per row.
 template <bool VEC>
@@ -444,7 +670,21 @@ static int band_lanes(int T, int S, int r) {
   if (r <= 15 && band_lds_bytes<16>(T, S) <= (size_t)150 * 1024) return 16;
   return 0;
 }
-int mi_band_supported(int T, int S, int r) { return band_lanes(T, S, r) != 0 ? 1 : 0; }
+// 0: not supported; 1: the LDS-resident kernel; 2: the streaming kernel (needs mi_band_workspace_floats() floats of workspace)
+static int band_stream_lanes(int T, int r) {
+  if (r < 1 || r > 15 || band_stream_lds_bytes(T) > (size_t)150 * 1024) return 0;
+  return r <= 7 ? 8 : 16;
+}
+int mi_band_supported(int T, int S, int r) {
+  static const bool force_stream = getenv("FTR_BAND_FORCE_STREAM") != nullptr;   // test knob: every size through the streaming kernel
+  if (!force_stream && band_lanes(T, S, r) != 0) return 1;
+  return (T >= 1 && S >= 0 && band_stream_lanes(T, r) != 0) ? 2 : 0;
+}
+size_t mi_band_workspace_floats(int B, int T, int S, int r) {
+  if (mi_band_supported(T, S, r) != 2) return 0;
+  const size_t per = band_stream_lanes(T, r) == 8 ? band_stream_floats_per_utt<8>(T, S) : band_stream_floats_per_utt<16>(T, S);
+  return per * (size_t)B;
+}
 
 int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,
                 const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C,
@@ -457,12 +697,37 @@ int band_gather(const float* logits, const int32_t* symbols, const int32_t* rang
   return check_launch("band_gather");
 }
 
-int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ans,
-            float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st) {
-  const int lanes = band_lanes(T, S, r);
-  if (!lanes) { set_error("mutual_information_band: T=%d S=%d r=%d does not fit the LDS-resident kernel", T, S, r); return FTR_ERR_UNSUPPORTED; }
+int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ws, size_t ws_floats,
+            float* ans, float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st) {
+  const int kind = mi_band_supported(T, S, r);
+  if (!kind) { set_error("mutual_information_band: T=%d S=%d r=%d is outside the band kernels' domain (r <= 15)", T, S, r); return FTR_ERR_UNSUPPORTED; }
   if ((uint64_t)(T + 1) * r * r >= (1ull << 32)) { set_error("mutual_information_band: T * r too large"); return FTR_ERR_UNSUPPORTED; }
   const unsigned rinv = (r == 1) ? 0u : (unsigned)(((1ull << 32) + r - 1) / r);   // i / r == umulhi(i, rinv) while i * (r - 1) < 2^32; 0 stands for r = 1
+  if (kind == 2) {
+    const size_t need = mi_band_workspace_floats(B, T, S, r);
+    if (!ws || ws_floats < need || (reinterpret_cast<uintptr_t>(ws) & 15) != 0) {
+      set_error("mutual_information_band: this size streams through a workspace of %zu floats (16-byte aligned), got %zu", need, ws_floats);
+      return FTR_ERR_INVALID_ARG;
+    }
+    const size_t lds = band_stream_lds_bytes(T);
+    static bool big_ok = false;
+    if (!big_ok) {
+      const void* ks[4] = {reinterpret_cast<const void*>(mi_band_stream_kernel<true, 8>), reinterpret_cast<const void*>(mi_band_stream_kernel<false, 8>),
+                           reinterpret_cast<const void*>(mi_band_stream_kernel<true, 16>), reinterpret_cast<const void*>(mi_band_stream_kernel<false, 16>)};
+      for (const void* k : ks)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
+          (void)hipGetLastError(); set_error("mutual_information_band: cannot raise the dynamic LDS limit"); return FTR_ERR_LAUNCH;
+        }
+      big_ok = true;
+    }
+#define FTR_BANDS_LAUNCH(MODV, LV) hipLaunchKernelGGL((mi_band_stream_kernel<MODV, LV>), dim3(B), dim3(kBandThreads), lds, st, \
+    pxb, pyb, ranges, boundary, ws, ans, gxb, gyb, B, T, S, r, rinv)
+    if (band_stream_lanes(T, r) == 8) { if (modified) FTR_BANDS_LAUNCH(true, 8); else FTR_BANDS_LAUNCH(false, 8); }
+    else { if (modified) FTR_BANDS_LAUNCH(true, 16); else FTR_BANDS_LAUNCH(false, 16); }
+#undef FTR_BANDS_LAUNCH
+    return check_launch("mi_band_stream");
+  }
+  const int lanes = band_lanes(T, S, r);
   static bool big_ok = false;
   if (!big_ok) {   // 156 KB: the kernel also has a few bytes of static LDS (__syncthreads_or)
     const void* ks[4] = {reinterpret_cast<const void*>(mi_band_kernel<true, 8>), reinterpret_cast<const void*>(mi_band_kernel<false, 8>),

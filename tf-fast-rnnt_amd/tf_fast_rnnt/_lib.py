@@ -67,6 +67,8 @@ _SIGNATURES = {
     "ftr_mutual_information_band_supported": (_i, [_i, _i, _i]),
     "ftr_pruned_band_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_band_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_mutual_information_band_workspace_floats": (ctypes.c_size_t, [_i, _i, _i, _i]),
+    "ftr_mutual_information_band_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_ip, _c_fp, ctypes.c_size_t, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_pruned_band_bwd_scaled_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, _c_fp, _c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_bwd_w_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),

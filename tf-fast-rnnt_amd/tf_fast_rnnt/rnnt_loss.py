@@ -603,14 +603,14 @@ def _band_path_ok(ranges, T: int, S: int, r: int) -> bool:
     """The band-native recursion needs monotone ranges (only get_rnnt_prune_ranges' own output is known to be) and a band
     that fits its LDS-resident kernel."""
     return bool(getattr(ranges, "_ftr_monotone", False)) and \
-        _lib.lib().ftr_mutual_information_band_supported(int(T), int(S), int(r)) == 1
+        _lib.lib().ftr_mutual_information_band_supported(int(T), int(S), int(r)) != 0
 
 
 class _PrunedLoss(torch.autograd.Function):
     """rnnt_loss_pruned for regular/modified with the whole chain native.
 
     Band path (ranges from get_rnnt_prune_ranges, band fits the kernel): logsumexp + band gather -> forward recursion,
-    cut and backward recursion on the band [B,T,r] in one launch (ftr_mutual_information_band_f32; no full-size lattice
+    cut and backward recursion on the band [B,T,r] in one launch (ftr_mutual_information_band_ws_f32; no full-size lattice
     exists) -> in backward() one streaming kernel turns the band-shaped occupancies * upstream gradient into
     d loss / d logits.
     Lattice path (any other ranges): logsumexp + band->lattice, recursion forward / backward on the full-size lattices
@@ -636,8 +636,11 @@ class _PrunedLoss(torch.autograd.Function):
                 _lib.call("ftr_pruned_band_fwd_f32", _ptr(x), _ptr(symbols), _ptr(ranges), _ptr(boundary),
                           int(termination_symbol), float(delay_penalty), _ptr(lse), _ptr(pxb), _ptr(pyb),
                           B, T, S, C, r, int(modified), st)
-                _lib.call("ftr_mutual_information_band_f32", _ptr(pxb), _ptr(pyb), _ptr(ranges), _ptr(boundary), _ptr(ans),
-                          _ptr(gxb), _ptr(gyb), B, T, S, r, int(modified), st)
+                nws = _lib.lib().ftr_mutual_information_band_workspace_floats(B, T, S, r)   # 0: the LDS-resident kernel
+                bws = torch.empty((nws,), dtype=torch.float32, device=x.device) if nws else None
+                _lib.call("ftr_mutual_information_band_ws_f32", _ptr(pxb), _ptr(pyb), _ptr(ranges), _ptr(boundary), _ptr(bws),
+                          nws, _ptr(ans), _ptr(gxb), _ptr(gyb), B, T, S, r, int(modified), st)
+                del bws
             del pxb, pyb
             if need:
                 ctx.save_for_backward(x, symbols, ranges, lse, gxb, gyb,
