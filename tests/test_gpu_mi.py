@@ -495,3 +495,18 @@ def test_recursion_fuzz_against_plain_kernels(ft, dev):
     spec = importlib.util.spec_from_file_location("mi_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "mi_fuzz.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     m.main(150, 20261004)
+
+
+def test_streaming_band_kernel_on_every_size(dev):
+    """The streaming band kernel (long utterances: arrays in a global workspace) on the SMALL cases too: FTR_BAND_FORCE_STREAM
+    (read once per process, hence child processes) sends every size through it -- the edge-case test above and the
+    route-vs-route fuzz of scripts/band_fuzz.py."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FTR_BAND_FORCE_STREAM="1")
+    r1 = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_mi.py"), "-q", "-x", "-m", "gpu", "-k",
+                         "band_recursion_kernel_edge_cases", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, os.path.join(root, "scripts", "band_fuzz.py"), "150", "31"], env=env, cwd=root, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0 and "band route == lattice route" in r2.stdout, r2.stdout[-2000:] + r2.stderr[-2000:]
