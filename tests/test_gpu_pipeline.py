@@ -697,3 +697,32 @@ def test_whole_pipeline_fuzz_against_oracle(ft, dev, oracle):
         if f.any():
             np.testing.assert_allclose(loss.detach().cpu().numpy()[f], o_loss[f], rtol=1e-4, atol=1e-5)
             assert max_rel(logits.grad.cpu().numpy()[f], o_g[f]) <= 2e-4, (it, B, T, S, C, r, rt)
+
+
+def test_gemm_kernel_selection_switch(ft, dev, tmp_path):
+    """tune_normalizer_gemms (PyTorch TunableOp over rocBLAS / hipBLASLt for the library GEMMs that remain in the builders'
+    backward): switching it on changes which library kernel runs, not the result (1e-5 normwise), the choices land in the
+    given file, and switching it off restores the default."""
+    import torch.cuda.tunable as tunable
+    d = synthetic(5, 2, 70, 33, 24, ragged=True)
+    sym, bd = _t(d["symbols"], dev), _t(d["boundary"], dev)
+
+    def grads():
+        lm = _t(d["lm"], dev).requires_grad_(True); am = _t(d["am"], dev).requires_grad_(True)
+        ft.rnnt_loss_simple(lm, am, sym, d["termination_symbol"], boundary=bd, reduction="sum").backward()
+        return am.grad.cpu().numpy(), lm.grad.cpu().numpy()
+
+    ref = grads()
+    path = str(tmp_path / "gemm_choices.csv")
+    try:
+        ft.tune_normalizer_gemms(True, path)
+        assert tunable.is_enabled() and tunable.tuning_is_enabled() and tunable.get_filename() == path
+        got = grads()
+    finally:
+        ft.tune_normalizer_gemms(False)
+    assert not tunable.is_enabled()
+    for g, r_ in zip(got, ref):
+        assert np.abs(g - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max())
+    again = grads()
+    for g, r_ in zip(again, ref):
+        assert np.array_equal(g, r_)
