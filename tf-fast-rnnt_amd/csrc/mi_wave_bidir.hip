@@ -147,14 +147,15 @@ __device__ __forceinline__ Cut make_cut(int Sn, int Tn) {
   return c;
 }
 
-// input tiles: 3 buffers (chunk k+2 is being parked while chunk k+1 is read into registers and chunk k is computed from
-// registers); output tiles: 2 buffers (chunk k is written while chunk k-1 is drained).  (k) + 3 keeps the index
-// non-negative for the warm-up slots.
-#define FTR_TX(k) (lds + (((k) + 3) % 3) * TILE_F4)
-#define FTR_TY(k) (lds + (3 + ((k) + 3) % 3) * TILE_F4)
-#define FTR_TD(k) (lds + (6 + ((k) & 1)) * TILE_F4)
-#define FTR_TP(k) (lds + (8 + ((k) & 1)) * TILE_F4)
-constexpr int kFwdTiles = 10;
+// input tiles: 4 buffers (steady state: chunk k+2 is being parked while chunk k+1 is read into registers and chunk k is
+// computed from registers; a chained band parks chunks 0..3 before it computes chunk 0 -- see the IO-in wave); output
+// tiles: 2 buffers (chunk k is written while chunk k-1 is drained).  (k) + 8
+// keeps the index non-negative for the warm-up slots.
+#define FTR_TX(k) (lds + (((k) + 8) & 3) * TILE_F4)
+#define FTR_TY(k) (lds + (4 + (((k) + 8) & 3)) * TILE_F4)
+#define FTR_TD(k) (lds + (8 + ((k) & 1)) * TILE_F4)
+#define FTR_TP(k) (lds + (10 + ((k) & 1)) * TILE_F4)
+constexpr int kFwdTiles = 12;
 constexpr int kFlowThreads = 320;   // flow kernel: compute, IO-in, COMM (loads only), IO-out px + hand-off stores, IO-out py
 constexpr int kAhead = 2;   // the IO-in wave parks chunk kc + kAhead during slot kc
 
@@ -173,7 +174,10 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   // start of slot kc + 1 for its chunk kc + 1, which needs the upper chunk kc + 1 + 4 (regular: lane 0's neighbour is
   // 63 steps ahead, plus one carried element) / kc + 1 (modified)
   constexpr int LOOK = MOD ? 1 : 5;
-  constexpr int PRE = NPF + kAhead;  // IO pipeline warm-up slots in front of chunk 0
+  // IO pipeline warm-up slots in front of chunk 0: NPF + kAhead, and NPF more in a band that has a band above it (whose
+  // first four chunks are parked early, see the IO-in wave)
+  const bool chained = w > 0;
+  const int PRE = NPF + kAhead + (chained ? NPF : 0);
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 compute, 1 IO-in, 2 COMM, 3 IO-out
   const int T1 = MOD ? T : T + 1;
@@ -455,38 +459,6 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     }
     return g;
   };
-  auto drain_general = [&](int k) {
-    const f4* sD = FTR_TD(k);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = 16 * m + frow;
-      const int r = row0 + row;
-      if (r < Sn) {
-        const int c0 = CH * k + 4 * fq - SKEW * row;
-        const f4 g = to_G(sD[fq * PLANE + row]);
-        if (!REVM) {
-          const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
-          if (c0 >= 0 && c0 + 3 < Tn) {
-            *reinterpret_cast<f4u*>(wsb + o) = g;
-          } else if (c0 + 3 >= 0 && c0 < Tn) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c0 + e >= 0 && c0 + e < Tn) wsb[o + e] = g[e];
-          }
-        } else {
-          const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
-          if (c0 >= 0 && c0 + 3 < Tn) {
-            *reinterpret_cast<f4u*>(wsb + lo) = rev4(g);
-          } else if (c0 + 3 >= 0 && c0 < Tn) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c0 + e >= 0 && c0 + e < Tn) wsb[lo + 3 - e] = g[e];
-          }
-        }
-      }
-    }
-  };
-
   // ---- interior ("fast") chunks: every quad of every lane-row lies inside [1, Tn) in columns, so loads and
   // stores are plain 16-byte accesses with no per-element guards and no divergent control flow.  Rows
   // beyond the utterance are clamped to a valid row: what they compute never reaches a valid row (data
@@ -543,6 +515,34 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     }
   };
 
+  // edge chunks: the same reads and the same precomputed offsets; a quad that lies inside the rectangle is stored whole, one
+  // that straddles its edge element by element (in start chunk k only the rows 16k .. 16k+15 have such a quad, so three
+  // of the four row groups skip that branch).  Per-quad 64-bit addresses here (the first version) made these slots 0.95 us
+  // against the 0.7 us of the steady state, in the first four slots of every band.
+  auto drain_edge = [&](int k) {
+    const f4* sD = FTR_TD(k);
+    float* ws_k = REVM ? wsb - CH * k : wsb + CH * k;
+    f4 v[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v[m] = sD[fq * PLANE + 16 * m + frow];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f4 g = to_G(v[m]);
+      const int c0 = CH * k + 4 * fq - SKEW * (16 * m + frow);   // walk column of the quad's first step
+      if (rvalid[m]) {
+        float* dst = ws_k + offG[m];
+        if (c0 >= 0 && c0 + 3 < Tn) {
+          *reinterpret_cast<f4u*>(dst) = REVM ? rev4(g) : g;
+        } else if (c0 + 3 >= 0 && c0 < Tn) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e >= 0 && c0 + e < Tn) dst[REVM ? 3 - e : e] = g[e];
+        }
+      }
+    }
+  };
+
   const int K0 = MOD ? 1 : 4;                                      // 16k - 63*SKEW >= 1
 #ifdef FTR_EXP_ALLGENERIC
   const int K1 = 0;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       clear_imported(kc - 1 + LOOK);
       if (k >= 0 && k < klast) {
         if (k >= K0 && k < K1) drain_fast(k);   // wave-uniform
-        else drain_general(k);
+        else drain_edge(k);
       }
       FTR_SYNC();
     }
@@ -592,63 +592,51 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   // --------------------------------------------------------------------------- IO-in
   // degenerate slabs (fewer than 4 elements of px or py per utterance, or no px at all): guarded element loads
   const bool tiny = xmaxo < 0 || ymaxo < 0;
-  auto slot_general = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    if (kc + kAhead >= 0 && kc + kAhead < klast) park(kc + kAhead, x, y, std::false_type{}, offX, offY);
-    if (kc + kAhead + NPF >= 0 && kc + kAhead + NPF < klast) load_general(kc + kAhead + NPF, x, y);
-    FTR_SYNC();
-  };
   // an edge chunk has quads outside [1, Tn); readfirstlane: the compiler must see the flag as wave-uniform, or it runs
   // the masking code under an exec mask in every slot (seen: the slot of this wave doubled)
   auto is_edge = [&](int k) { return __builtin_amdgcn_readfirstlane((int)!(k >= K0 && k < K1)) != 0; };
-  // pipeline fill and drain: the chunk to park / to load may not exist
-  auto slot_cond = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    const int kp = kc + kAhead, kl = kc + kAhead + NPF;
+  // One loop for every slot; slot gg = kc - base uses register set gg % NPF.  Steady schedule: park the chunk this set
+  // holds (loaded NPF slots ago, computed kAhead slots from now), load the chunk NPF further on.  Past the last chunk the
+  // loads are still issued, with every lane's address clamped to the same 16 bytes (no bandwidth, the values are never
+  // parked): a load under a condition turns every wait of the loop into vmcnt(0), and so did a separate warm-up loop with
+  // a forced vmcnt(0) behind it (the first park waited for four chunks' cold misses, 2.2 us in band 0's trace).
+  //
+  // A chained band (one with a band above it) starts differently.  Its first four chunks are edge chunks, whose parks take
+  // 1.1-1.4 us against the 0.7 us slot of the steady state (scripts/mi_trace_waves.py), and in the steady schedule they
+  // sit in the slots in which the band already follows the band above at that band's steady pace: every band fell a
+  // further ~2 us behind, for good.  Such a band runs NPF more warm-up slots: it loads chunks 0..3 in slots 0..3 and parks
+  // them in slots 4..7, while its COMM wave still waits for the first granules (four input tiles, so that all four fit);
+  // slots 8..11 park nothing (they load again what the sets already hold: the registers must stay valid) and the steady
+  // schedule resumes with chunk 4 in slot 12.  Every chunk still lives in set (chunk % NPF) and is parked NPF slots after
+  // its (last) load, so the compiler's counted waits hold for both schedules.
+  // Same box, head -> this (us): c3 53.4 -> 48.9, B=8 46.8 -> 44.3, c5 and B=256 unchanged, c4 112-114 -> 115-116.
+  static_assert(NPF == 4, "the early parks assume four register sets and four input tiles");
+  constexpr int kNoChunk = 1 << 20;   // CH * kNoChunk is beyond any slab (and far from overflowing an int offset)
+  auto slot_any = [&](int gg, f4 (&x)[4], f4 (&y)[4]) {
+    const int kp = chained ? (gg < 2 * NPF ? gg - NPF : (gg < 3 * NPF ? -1 : gg - 2 * NPF)) : gg - NPF;
+    const int kl = chained && gg >= 2 * NPF ? gg - NPF : gg;
     if (kp >= 0 && kp < klast) {
       if (is_edge(kp)) park(kp, x, y, std::true_type{}, offX, offY);
       else park(kp, x, y, std::false_type{}, offX, offY);
     }
-    if (kl >= 0 && kl < klast) load_fast(kl, x, y);
+    load_fast(kl < klast ? kl : kNoChunk, x, y);
     FTR_SYNC();
   };
-  auto slot_steady = [&](int kc, f4 (&x)[4], f4 (&y)[4]) {
-    const int kp = kc + kAhead;
-    // loads of chunk kp were issued NPF slots ago; VALU / LDS work only inside the (wave-uniform) branch
-    if (is_edge(kp)) park(kp, x, y, std::true_type{}, offX, offY);
-    else park(kp, x, y, std::false_type{}, offX, offY);
-    load_fast(kp + NPF, x, y);
-    FTR_SYNC();
-  };
-
-  // steady slot kc: the parked chunk kc+kAhead and the loaded chunk kc+kAhead+NPF both exist
-  const int KF0 = -kAhead, KF1 = tiny ? KF0 : klast - kAhead - NPF;      // steady slots: KF0 <= kc < KF1
-  int it1 = (KF0 - base + NPF - 1) / NPF;                // first iteration whose first slot has kc >= KF0
-  int it2 = (KF1 - base) / NPF;                          // first iteration whose last slot has kc >= KF1
-  it1 = min(max(it1, 0), NIT);
-  it2 = min(max(it2, it1), NIT);
-
-  int it = 0;
   if (tiny) {
-    for (; it < NIT; ++it) {
+    for (int it = 0; it < NIT; ++it) {
 #pragma unroll
-      for (int u = 0; u < NPF; ++u) slot_general(base + NPF * it + u, rx[u], ry[u]);
+      for (int u = 0; u < NPF; ++u) {
+        const int kc = base + NPF * it + u;
+        if (kc + kAhead >= 0 && kc + kAhead < klast) park(kc + kAhead, rx[u], ry[u], std::false_type{}, offX, offY);
+        if (kc + kAhead + NPF >= 0 && kc + kAhead + NPF < klast) load_general(kc + kAhead + NPF, rx[u], ry[u]);
+        FTR_SYNC();
+      }
     }
-  }
-  for (; it < it1; ++it) {
+  } else {
+    for (int it = 0; it < NIT; ++it) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) slot_cond(base + NPF * it + u, rx[u], ry[u]);
-  }
-  if (it < it2) {
-    // nothing pending when the steady-state loop is entered: with a known state at both loop entries the compiler
-    // keeps the waits inside the loop counted (vmcnt(n > 0)) instead of falling back to vmcnt(0) in every slot
-    __builtin_amdgcn_s_waitcnt(kVmcnt0);
-    for (; it < it2; ++it) {
-#pragma unroll
-      for (int u = 0; u < NPF; ++u) slot_steady(base + NPF * it + u, rx[u], ry[u]);
+      for (int u = 0; u < NPF; ++u) slot_any(NPF * it + u, rx[u], ry[u]);
     }
-  }
-  for (; it < NIT; ++it) {
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) slot_cond(base + NPF * it + u, rx[u], ry[u]);
   }
   if (__any(nan_acc > 0x7f800000u) && lane == 0) __hip_atomic_fetch_or(uflag_b, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   FTR_SYNC_REPORT(1);
@@ -1293,7 +1281,7 @@ __global__ __launch_bounds__(kFlowThreads) void mi_bidir_flow_kernel(
 #endif
 }
 
-inline size_t bidir_lds_bytes() { return (size_t)kFwdTiles * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }   // forward: 10 tiles + ring; flow: 9 tiles + ring
+inline size_t bidir_lds_bytes() { return (size_t)kFwdTiles * TILE_F4 * sizeof(f4) + 2 * RINGN * sizeof(float); }   // forward: 12 tiles + ring; flow: 9 tiles + ring
 
 // The workgroup dispatcher fills a CU up to its resource limits before it moves on: with 26 KB of LDS per workgroup
 // it co-locates workgroups on a few CUs of each XCD while others idle, and the co-located compute waves (one chain
