@@ -421,6 +421,17 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       const int row = 16 * m + frow;
       f4 xm = xin[m], ym = yin[m];
       const int c0 = CH * kk + 4 * fq - SKEW * row;   // walk column of the quad's first step
+      if (edge) {
+        // a row group none of whose columns lies in the rectangle (start chunk k of the regular type: the groups m > k
+        // have not reached column 0 yet -- three of the four in chunk 0): nothing to mask, scale or check
+        const int cmax = CH * kk + 15 - SKEW * 16 * m, cmin = CH * kk - SKEW * (16 * m + 15);   // wave-uniform
+        if (cmax < NOFF || cmin >= Tn) {
+          const f4 nothing = {kNeg, kNeg, kNeg, kNeg};
+          dX[fq * PLANE + row] = nothing;
+          dY[fq * PLANE + row] = nothing;
+          continue;
+        }
+      }
       if (edge) {   // the chunk has quads outside [1, Tn)
         const int dk = REVM ? -CH * kk : CH * kk;
         const int wx = offXr[m] + dk, wy = offYr[m] + dk;
@@ -528,6 +539,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+      if (CH * k + 15 - SKEW * 16 * m < 0 || CH * k - SKEW * (16 * m + 15) >= Tn) continue;   // wave-uniform: no column of this row group lies in the rectangle
       const f4 g = to_G(v[m]);
       const int c0 = CH * k + 4 * fq - SKEW * (16 * m + frow);   // walk column of the quad's first step
       if (rvalid[m]) {
