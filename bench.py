@@ -214,7 +214,7 @@ def algorithmic_bytes(B, T, S, C, r):
         "ftr_mutual_information_fwd_ws_f32": 4 * (npx + npy + L),
         "ftr_mutual_information_bwd_ws_f32": 4 * (npx + npy + L + npx + npy),
         "ftr_prune_ranges_i32": 4 * (npx + npy + B * T * r),
-        "ftr_do_pruning_f32": 4 * (B * T * C + B * (S + 1) * C + B * T * r) + 2 * N,
+        "ftr_do_pruning_f32": 4 * (B * (S + 1) * C + B * T * r) + N,     # the gather; am_pruned stays a broadcast view of am
         "ftr_pruned_logprobs_fwd_f32": N + 4 * (npx + npy),              # stream logits once, write px,py
         # the band path of rnnt_loss_pruned (3 N + O(B T r) for the pruned loss with a banded DP)
         "ftr_pruned_band_fwd_f32": N + 4 * 3 * B * T * r,                # stream logits once; lse, px_band, py_band

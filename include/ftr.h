@@ -138,7 +138,9 @@ int ftr_prune_ranges_i32(const float* px_grad, const float* py_grad, const int32
 
 /* Prune gather.  Replaces do_rnnt_pruning (rnnt_loss.py:763-812):
  * am_pruned[b,t,k,:] = am[b,t,:], lm_pruned[b,t,k,:] = lm[b,ranges[b,t,k],:].
- * am [B,T,C], lm [B,S1,C], ranges [B,T,r]; outputs [B,T,r,C]. */
+ * am [B,T,C], lm [B,S1,C], ranges [B,T,r]; outputs [B,T,r,C].
+ * am_pruned may be NULL: only lm_pruned is produced (am_pruned is a broadcast of am over r; a host whose tensors
+ * have strides keeps it as a view -- the shipped Python package does -- and saves B*T*r*C*4 bytes of writes). */
 int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, float* am_pruned,
                        float* lm_pruned, int B, int T, int S1, int C, int r, void* stream);
 

@@ -87,6 +87,39 @@ def test_do_pruning_bit_exact_and_grad(ft, dev, oracle, C):
     np.testing.assert_allclose(lm.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
 
 
+def test_do_pruning_am_is_a_broadcast_view_and_the_c_abi_still_materialises(ft, dev, oracle):
+    """am_pruned[b,t,k,:] = am[b,t,:] (rnnt_loss.py:803, a tf.broadcast_to).  The package returns it as a stride-0 view over
+    s_range (no B*T*r*C write), with the reference's values, shape and gradient; .contiguous() gives the dense tensor.  The
+    C ABI writes both dense outputs when given two pointers and only the gather when am_pruned is NULL."""
+    from tf_fast_rnnt import _lib
+    from tf_fast_rnnt.mutual_information import _ptr
+    d = synthetic(2, 3, 30, 11, 24, ragged=True)
+    _, gx, gy = _occupancies(oracle, d)
+    ranges = oracle.get_rnnt_prune_ranges(gx, gy, d["boundary"], 4)
+    o_am, o_lm = oracle.do_rnnt_pruning(d["am"], d["lm"], ranges)
+    am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
+    rg = _t(ranges, dev)
+    am_p, lm_p = ft.do_rnnt_pruning(am, lm, rg)
+    B, T, r = ranges.shape
+    C = d["am"].shape[2]
+    assert tuple(am_p.shape) == (B, T, r, C) and am_p.stride(2) == 0 and lm_p.is_contiguous()
+    assert np.array_equal(am_p.detach().contiguous().cpu().numpy(), o_am) and np.array_equal(lm_p.detach().cpu().numpy(), o_lm)
+    # a joiner consumes it by broadcasting; the gradient is the sum over s_range of what comes back
+    w = torch.randn((B, T, r, C), device=dev)
+    (torch.tanh(am_p + lm_p) * w).sum().backward()
+    g = (w * (1 - torch.tanh(_t(o_am, dev) + _t(o_lm, dev)) ** 2))
+    np.testing.assert_allclose(am.grad.cpu().numpy(), g.sum(dim=2).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the C ABI: dense am_pruned when asked for, untouched when NULL
+    dense_am = torch.full((B, T, r, C), -7.0, device=dev); dense_lm = torch.empty((B, T, r, C), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    S1 = d["lm"].shape[1]
+    _lib.call("ftr_do_pruning_f32", _ptr(am.detach()), _ptr(lm.detach()), _ptr(rg), _ptr(dense_am), _ptr(dense_lm), B, T, S1, C, r, st)
+    assert np.array_equal(dense_am.cpu().numpy(), o_am) and np.array_equal(dense_lm.cpu().numpy(), o_lm)
+    only_lm = torch.empty((B, T, r, C), device=dev)
+    _lib.call("ftr_do_pruning_f32", _ptr(am.detach()), _ptr(lm.detach()), _ptr(rg), None, _ptr(only_lm), B, T, S1, C, r, st)
+    assert np.array_equal(only_lm.cpu().numpy(), o_lm)
+
+
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
 def test_pruned_logprobs_exact_pattern(ft, dev, oracle, rnnt_type):
     d = reference_test_recipe(1234, 2, 40, 12, 16)

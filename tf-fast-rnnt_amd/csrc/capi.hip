@@ -186,7 +186,7 @@ int ftr_do_pruning_f32(const float* am, const float* lm, const int32_t* ranges, 
   clear_error();
   FTR_REQUIRE(B >= 0 && T >= 0 && S1 >= 1 && C >= 0 && r >= 0, "do_pruning: bad sizes");
   if ((size_t)B * T * r * C == 0) return FTR_OK;
-  FTR_REQUIRE(am && lm && ranges && am_pruned && lm_pruned, "do_pruning: null pointer");
+  FTR_REQUIRE(am && lm && ranges && lm_pruned, "do_pruning: null pointer");   // am_pruned may be NULL: gather only
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   return do_pruning(am, lm, ranges, am_pruned, lm_pruned, B, T, S1, C, r, reinterpret_cast<hipStream_t>(stream));

@@ -237,6 +237,8 @@ __global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict
                                                          float* __restrict__ lm_p, int T, int S1, int C, int r) {
   // one block per frame (b,t): the am row is read once and written r times, the r lm rows are gathered; the outputs
   // (2 * N bytes, far beyond any cache) are written with non-temporal stores.  No per-thread index divisions.
+  // am_p == nullptr: only the gather (the host keeps am_pruned as a broadcast view of am, which is all it is).
+  const bool copy_am = am_p != nullptr;
   const size_t bt = blockIdx.x;
   const size_t b = bt / T;
   const int32_t* rg = ranges + bt * r;
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict
     const int n4 = C >> 2;
     const f4u* arow = reinterpret_cast<const f4u*>(am + bt * C);
     for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
-      const f4 a = arow[c4];
+      f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (copy_am) a = arow[c4];
       for (int k0 = 0; k0 < r; k0 += 8) {
         f4 l[8];
 #pragma unroll
@@ -256,16 +259,16 @@ __global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (k0 + u < r) {
-            __builtin_nontemporal_store(a, reinterpret_cast<f4u*>(ao + (size_t)(k0 + u) * C) + c4);
+            if (copy_am) __builtin_nontemporal_store(a, reinterpret_cast<f4u*>(ao + (size_t)(k0 + u) * C) + c4);
             __builtin_nontemporal_store(l[u], reinterpret_cast<f4u*>(lo + (size_t)(k0 + u) * C) + c4);
           }
       }
     }
   } else {
     for (int c = threadIdx.x; c < C; c += 128) {
-      const float a = am[bt * C + c];
+      const float a = copy_am ? am[bt * C + c] : 0.0f;
       for (int k = 0; k < r; ++k) {
-        ao[(size_t)k * C + c] = a;
+        if (copy_am) ao[(size_t)k * C + c] = a;
         lo[(size_t)k * C + c] = lmb[(size_t)min(max(rg[k], 0), S1 - 1) * C + c];
       }
     }

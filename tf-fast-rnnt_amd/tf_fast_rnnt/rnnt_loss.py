@@ -485,10 +485,14 @@ class _DoPruning(torch.autograd.Function):
         B, T, r = ranges.shape
         S1, C = lm.shape[1], lm.shape[2]
         am_c = am.detach().contiguous(); lm_c = lm.detach().contiguous()
-        am_p = torch.empty((B, T, r, C), dtype=am.dtype, device=am.device)
+        # am_pruned[b,t,k,:] = am[b,t,:] for every k (rnnt_loss.py:803): a broadcast.  TensorFlow has no strided tensors and
+        # materialises it; here it stays a stride-0 view (as k2's fast_rnnt returns it), which a joiner's `am_pruned +
+        # lm_pruned` consumes by broadcasting: B*T*r*C*4 bytes less to write here and to read there.  Values, shape and the
+        # gradient (the sum over r, in the fused backward below) are the reference's; .contiguous() gives the dense tensor.
+        am_p = am_c.unsqueeze(2).expand(B, T, r, C)
         lm_p = torch.empty((B, T, r, C), dtype=lm.dtype, device=lm.device)
         with torch.cuda.device(am.device):
-            _lib.call("ftr_do_pruning_f32", _ptr(am_c), _ptr(lm_c), _ptr(ranges), _ptr(am_p), _ptr(lm_p),
+            _lib.call("ftr_do_pruning_f32", _ptr(am_c), _ptr(lm_c), _ptr(ranges), None, _ptr(lm_p),
                                                      B, T, S1, C, r, _stream_ptr(am))
         ctx.save_for_backward(ranges)
         ctx.lm_shape = tuple(lm.shape)
