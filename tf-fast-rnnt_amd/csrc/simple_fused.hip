@@ -40,7 +40,23 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][ROWS][kFLD]: rows 0..63 frames, then 16 NS symbol rows
   constexpr int ROWS = kFT + 16 * NS;
   constexpr int NU = (ROWS * 8 + 255) / 256;      // 16-byte pieces per thread and chunk
-  const int b = blockIdx.z, t0 = blockIdx.x * kFT, s0 = blockIdx.y * 16 * NS;
+  // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and every XCD has its own L2: in
+  // launch order the frame tiles that share one utterance's lm_probs rows (416 KB at c3) are spread over all eight, and each
+  // L2 fetches them again (PMC: 327 MB fetched for 77 MB of operands).  Here XCD k works through a contiguous eighth of the
+  // tile list instead, in four interleaved streams, so that the ~64 workgroups an XCD runs at a time share four sets of rows:
+  // c3 115 -> 106 us, c5 937 -> 920.  Only while four such sets fit the L2 beside the am stream (<= 512 KB each): at c4
+  // (852 KB) the same order costs 12 %, as does one stream of 64 workgroups on the same lines.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 31u) == 0 && (size_t)16 * NS * C * sizeof(float) <= 512 * 1024) {
+      const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned per = total >> 3, slot = lin >> 3;
+      const unsigned j = (lin & 7u) * per + (slot & 3u) * (per >> 2) + (slot >> 2);
+      bx = j % gridDim.x; by = (j / gridDim.x) % gridDim.y; bz = j / (gridDim.x * gridDim.y);
+    }
+  }
+  const int b = bz, t0 = bx * kFT, s0 = by * 16 * NS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T1 = MOD ? T : T + 1;
