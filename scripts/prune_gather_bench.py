@@ -14,5 +14,5 @@ torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.c
 e0.record()
 for _ in range(20): ft.do_rnnt_pruning(am, lm, ranges)
 e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) * 1000 / 20; mb = (2 * B * T * r * C + B * T * C + B * (S + 1) * C) * 4 / 1e6
+us = e0.elapsed_time(e1) * 1000 / 20; mb = (B * T * r * C + B * (S + 1) * C + B * T * r) * 4 / 1e6   # the gather; am_pruned is a broadcast view
 print(f"[{os.path.basename(os.environ.get('FTR_LIB_PATH', 'product'))}] do_rnnt_pruning B={B} T={T} S={S} C={C} r={r}: {us:.1f} us ({mb / us:.2f} TB/s algorithmic)")

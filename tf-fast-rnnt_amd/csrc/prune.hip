@@ -239,7 +239,11 @@ __global__ __launch_bounds__(128) void do_pruning_kernel(const float* __restrict
   // (2 * N bytes, far beyond any cache) are written with non-temporal stores.  No per-thread index divisions.
   // am_p == nullptr: only the gather (the host keeps am_pruned as a broadcast view of am, which is all it is).
   const bool copy_am = am_p != nullptr;
-  const size_t bt = blockIdx.x;
+  // XCD-aware frame order: workgroups are dealt to the 8 XCDs round robin and every XCD has its own L2; in launch order each
+  // of them fetches every utterance's lm rows.  Here XCD k takes a contiguous eighth of the frames: the rows of an utterance
+  // are fetched by one L2.
+  size_t bt = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) bt = (size_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const size_t b = bt / T;
   const int32_t* rg = ranges + bt * r;
   const float* lmb = lm + b * S1 * C;
