@@ -10,7 +10,7 @@ d = json.load(open('gpurun_out/bench.json'))
 print("graph", d.get("graph_replay")); print("ms/step", d["ms_per_step"], "value", d["value"], "native_us", d["native_us_per_step"], "peak MB", d["peak_mem_mb"], "roofline", d["roofline"])
 for k,v in d["kernels"].items(): print(f"  {k:40s} {v['avg_us']:8.1f} us x{v['calls_per_step']}  {v['GBps']} GB/s")
 PY
-timeout -k 10 300 python bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; rc=$?; echo "bench c4 exit $rc"
+timeout -k 10 300 python bench.py --config c4 --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; rc=$?; echo "bench c4 exit $rc"
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 python - <<'PY'
 import json
