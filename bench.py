@@ -518,7 +518,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.config}: rnnt_loss_pruned fwd+bwd step, B={B}/GPU T={T} S={S} C={C} s_range={r}, "
                                f"regular, {'ragged' if args.ragged else 'full'} boundary, first pass rnnt_loss_{first_pass}",
-                   "global_batch": world * B, "sharding": f"batch x{world}, one scalar all-reduce/step"},
+                   "global_batch": world * B, "sharding": f"batch x{world}, one scalar all-reduce/step",
+                   # do_rnnt_pruning returns am_pruned as a stride-0 broadcast view of am (values, shape and gradient as the
+                   # reference's tf.broadcast_to; the reference's joiner stand-in consumes it by broadcasting)
+                   "am_pruned": "broadcast view"},
         "roofline": roofline,
         "kernel_timing": f"HIP events around every native call on {len(sampled)} of the {args.steps} timed steps",
         "native_us_per_step": round(native_us, 1),
