@@ -26,9 +26,17 @@ def compute(inp, blank, s_ranges):
     out["simple_px"], out["simple_py"] = px, py
     loss, (gx, gy) = O.rnnt_loss_simple(lm, am, sym, blank, bd, reduction="none", calc_gradients=True)
     out["simple_loss"], out["simple_px_grad"], out["simple_py_grad"] = loss, gx, gy
+    # the same float32 px / py through the recursion in float64 (the *_f64 keys): the comparison point that carries no
+    # float32 log-domain noise of its own (at T = 200 the float32 recursion is 3e-4 away from it)
+    _, (gx64, gy64) = O.mutual_information_recursion(px, py, bd, True, np.float64)
+    out["simple_px_grad_f64"], out["simple_py_grad_f64"] = gx64.astype(np.float32), gy64.astype(np.float32)
     sl, (sgx, sgy) = O.rnnt_loss_smoothed(lm, am, sym, blank, lm_only_scale=0.1, am_only_scale=0.2, boundary=bd,
                                           reduction="none", delay_penalty=0.2, calc_gradients=True)
     out["smoothed_loss"], out["smoothed_px_grad"], out["smoothed_py_grad"] = sl, sgx, sgy
+    spx, spy = O.get_rnnt_logprobs_smoothed(lm, am, sym, blank, 0.1, 0.2, bd, "regular")
+    spx = O._delay_penalty(spx, bd, "regular", 0.2)
+    _, (sgx64, sgy64) = O.mutual_information_recursion(spx, spy, bd, True, np.float64)
+    out["smoothed_px_grad_f64"], out["smoothed_py_grad_f64"] = sgx64.astype(np.float32), sgy64.astype(np.float32)
     for r in s_ranges:
         ranges = O.get_rnnt_prune_ranges(sgx, sgy, bd, r)
         out[f"ranges_r{r}"] = ranges
@@ -37,6 +45,8 @@ def compute(inp, blank, s_ranges):
         pl, g = O.rnnt_loss_pruned_grad(logits, sym, ranges, blank, bd, delay_penalty=0.2, reduction="mean")
         out[f"pruned_loss_r{r}"] = np.asarray(pl, dtype=np.float32)
         out[f"pruned_logits_grad_r{r}"] = g
+        _, g64 = O.rnnt_loss_pruned_grad(logits, sym, ranges, blank, bd, delay_penalty=0.2, reduction="mean", dtype=np.float64)
+        out[f"pruned_logits_grad_r{r}_f64"] = g64
     return out
 
 

@@ -3,17 +3,21 @@ north_star tolerance ("ranges bit-exact; loss and px/py gradients within 1e-4 re
 
   c2  rnnt_loss_simple fwd+bwd, B=32 T=512 S=100 C=500            full size
   c3  pruned pipeline, T=1000 S=200 C=500 s_range=5               a B=2 batch slice at full T, S, C, r
+  c4  smoothed + pruned, T=2000 S=300 C=1024 s_range=5            a B=2 slice at full T, S, C, r (smoothed first pass
+                                                                  0.1 / 0.2, the streaming band kernel)
   c5  long form, T=8000 S=1000 C=512 s_range=10                   a B=1 slice at full T, S, C, r + the full B=8 pipeline
                                                                   through size-independent properties
-  (c1 and the reference test scenario: tests/golden fixtures, test_gpu_pipeline.py; c4: its per-GPU share there.)
+  (c1 and the reference test scenario: tests/golden fixtures, test_gpu_pipeline.py; c4's per-GPU share by properties there.)
 
 Every comparison records two error figures against the float32 oracle (= the reference's arithmetic) and against the
 float64 oracle: normwise  max|d| / max|ref|  and elementwise  max over entries with |ref| > 1e-6 max|ref|  of
-|d| / |ref|.  The session writes them to gpurun_out/parity_errors.json (committed as profiles/r02_parity_errors.json).
+|d| / |ref|.  The session writes them to gpurun_out/parity_errors.json (committed as profiles/r03_parity_errors.json).
 
-What is asserted.  Integer outputs: bit-exact.  Losses: 1e-4 elementwise against the float32 oracle.  Float lattices /
-gradients: normwise <= 1e-4 against the float32 oracle, or -- on lattices where the reference's own float32 arithmetic is
-further than that from float64 -- at least as close to the float64 oracle as the float32 oracle is.
+What is asserted.  Integer outputs: bit-exact.  Losses: 1e-4 elementwise against both oracles.  Float lattices /
+gradients: normwise <= 1e-4 (north_star's figure; TOL_F64) against the FLOAT64 oracle at every config -- since round 3 the
+recursion shifts its operands by per-utterance constants (csrc/ftr_common.h, Shift), which keeps float32 log-probabilities
+small where the occupancy is -- and against the float32 oracle (= the reference's arithmetic, which is itself 1e-3 ... 2e-2
+away from float64 on these lattices) only "at least as close to float64 as the float32 oracle is" (helpers.assert_parity).
 """
 import json
 import os
@@ -27,6 +31,7 @@ from helpers import assert_parity, max_rel, synthetic
 pytestmark = pytest.mark.gpu
 
 _LOG = {}
+TOL_F64 = 1e-4   # north_star: loss and px/py gradients within 1e-4 relative
 
 
 def _t(a, dev):
@@ -66,14 +71,18 @@ def _write_log():
         pass
 
 
-def _simple_pass_f64(oracle, d, px32, py32):
-    """float64 comparison point of the simple pass: float64 px/py builder, float64 recursion, and d am / d lm by
-    float64 torch autograd through the op-by-op restatement (occupancies chained into the builder)."""
-    from torch_restatements import get_rnnt_logprobs_torch
+def _simple_pass_f64(oracle, d, px32, py32, smoothed=None):
+    """float64 comparison point of the simple (or smoothed: smoothed = (lm_only_scale, am_only_scale)) pass: float64 px/py
+    builder, float64 recursion, and d am / d lm by float64 torch autograd through the op-by-op restatement (occupancies
+    chained into the builder)."""
+    from torch_restatements import get_rnnt_logprobs_torch, get_rnnt_logprobs_smoothed_torch
     lm = torch.from_numpy(d["lm"]).double().requires_grad_(True)
     am = torch.from_numpy(d["am"]).double().requires_grad_(True)
     sym = torch.from_numpy(d["symbols"]); bd = torch.from_numpy(d["boundary"])
-    px, py = get_rnnt_logprobs_torch(lm, am, sym, d["termination_symbol"], "regular", bd)
+    if smoothed is None:
+        px, py = get_rnnt_logprobs_torch(lm, am, sym, d["termination_symbol"], "regular", bd)
+    else:
+        px, py = get_rnnt_logprobs_smoothed_torch(lm, am, sym, d["termination_symbol"], smoothed[0], smoothed[1], bd, "regular")
     a64, (gx64, gy64) = oracle.mutual_information_recursion(px.detach().numpy(), py.detach().numpy(), d["boundary"], True, np.float64)
     fin = torch.isfinite(px)
     tot = -((torch.where(fin, px, torch.zeros_like(px)) * torch.from_numpy(gx64) * fin).sum() + (py * torch.from_numpy(gy64)).sum())
@@ -81,17 +90,23 @@ def _simple_pass_f64(oracle, d, px32, py32):
     return a64, gx64, gy64, am.grad.numpy(), lm.grad.numpy()
 
 
-def _check_simple_pass(ft, dev, oracle, config, d, tol_f64):
+def _check_simple_pass(ft, dev, oracle, config, d, tol_f64, smoothed=None):
     blank = d["termination_symbol"]
     am = _t(d["am"], dev).requires_grad_(True); lm = _t(d["lm"], dev).requires_grad_(True)
     sym, bd = _t(d["symbols"], dev), _t(d["boundary"], dev)
-    loss, (gx, gy) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank, boundary=bd,
-                                         reduction="none", calc_gradients=True)
+    if smoothed is None:
+        loss, (gx, gy) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank, boundary=bd,
+                                             reduction="none", calc_gradients=True)
+        o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], blank, "regular", d["boundary"])
+    else:
+        loss, (gx, gy) = ft.rnnt_loss_smoothed(lm=lm, am=am, symbols=sym, termination_symbol=blank, lm_only_scale=smoothed[0],
+                                               am_only_scale=smoothed[1], boundary=bd, reduction="none", calc_gradients=True)
+        o_px, o_py = oracle.get_rnnt_logprobs_smoothed(d["lm"], d["am"], d["symbols"], blank, smoothed[0], smoothed[1],
+                                                       d["boundary"], "regular")
     loss.sum().backward()
     torch.cuda.synchronize()
-    o_px, o_py = oracle.get_rnnt_logprobs(d["lm"], d["am"], d["symbols"], blank, "regular", d["boundary"])
     o_ans, (o_gx, o_gy) = oracle.mutual_information_recursion(o_px, o_py, d["boundary"], True)
-    a64, gx64, gy64, dam64, dlm64 = _simple_pass_f64(oracle, d, o_px, o_py)
+    a64, gx64, gy64, dam64, dlm64 = _simple_pass_f64(oracle, d, o_px, o_py, smoothed)
     loss_np, gx_np, gy_np = loss.detach().cpu().numpy(), gx.cpu().numpy(), gy.cpu().numpy()
     _record(config, "simple_loss", loss_np, -o_ans, -a64)
     np.testing.assert_allclose(loss_np, -o_ans, rtol=1e-4)
@@ -104,7 +119,7 @@ def _check_simple_pass(ft, dev, oracle, config, d, tol_f64):
     for name, got, r64 in (("d_am", am.grad.cpu().numpy(), dam64), ("d_lm", lm.grad.cpu().numpy(), dlm64)):
         e = dict(normwise_vs_f64=max_rel(got, r64), elementwise_vs_f64=_elem_rel(got, r64))
         _LOG.setdefault(config, {})["simple_" + name] = {k: float(f"{v:.3e}") for k, v in e.items()}
-        assert e["normwise_vs_f64"] <= max(1e-4, tol_f64), (config, name, e)
+        assert e["normwise_vs_f64"] <= tol_f64, (config, name, e)
     return gx_np, gy_np, o_gx, o_gy
 
 
@@ -143,21 +158,32 @@ def _check_pruned_pass(ft, dev, oracle, config, d, r, o_gx, o_gy, tol_f64):
 def test_c2_simple_loss_full_size(ft, dev, oracle):
     """BASELINE configs[1]: rnnt_loss_simple fwd+bwd B=32 T=512 S=100 C=500, ragged boundaries, full size."""
     d = synthetic(2, 32, 512, 100, 500, ragged=True)
-    _check_simple_pass(ft, dev, oracle, "c2_B32_T512_S100_C500", d, tol_f64=2e-4)
+    _check_simple_pass(ft, dev, oracle, "c2_B32_T512_S100_C500", d, tol_f64=TOL_F64)
 
 
 def test_c3_pruned_pipeline_batch_slice(ft, dev, oracle):
     """BASELINE configs[2] at full T, S, C, s_range with a B=2 slice (one full-size and one ragged utterance)."""
     d = synthetic(3, 2, 1000, 200, 500, ragged=True)
-    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c3_B2_T1000_S200_C500_r5", d, tol_f64=5e-4)
-    _check_pruned_pass(ft, dev, oracle, "c3_B2_T1000_S200_C500_r5", d, 5, o_gx, o_gy, tol_f64=5e-4)
+    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c3_B2_T1000_S200_C500_r5", d, tol_f64=TOL_F64)
+    _check_pruned_pass(ft, dev, oracle, "c3_B2_T1000_S200_C500_r5", d, 5, o_gx, o_gy, tol_f64=TOL_F64)
+
+
+def test_c4_smoothed_pruned_batch_slice(ft, dev, oracle):
+    """BASELINE configs[3] at full T, S, C (s_range = 5 as in bench.py) with a B=2 slice of one GPU's share: the smoothed
+    first pass (lm_only_scale 0.1, am_only_scale 0.2: the [C] = 1024 unigram path, the widest fused tiles), ranges, gather,
+    and the pruned pass, whose recursion runs in the STREAMING band kernel at this length."""
+    from tf_fast_rnnt import _lib
+    assert _lib.lib().ftr_mutual_information_band_supported(2000, 300, 5) == 2, "c4 is expected to take the streaming band kernel"
+    d = synthetic(4, 2, 2000, 300, 1024, ragged=True)
+    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c4_B2_T2000_S300_C1024_r5", d, tol_f64=TOL_F64, smoothed=(0.1, 0.2))
+    _check_pruned_pass(ft, dev, oracle, "c4_B2_T2000_S300_C1024_r5", d, 5, o_gx, o_gy, tol_f64=TOL_F64)
 
 
 def test_c5_long_form_batch_slice(ft, dev, oracle):
     """BASELINE configs[4] at full T, S, C, s_range = 10 with a B=1 slice: simple pass, ranges, gather, pruned pass."""
     d = synthetic(5, 1, 8000, 1000, 512, ragged=False)
-    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c5_B1_T8000_S1000_C512_r10", d, tol_f64=5e-3)
-    _check_pruned_pass(ft, dev, oracle, "c5_B1_T8000_S1000_C512_r10", d, 10, o_gx, o_gy, tol_f64=5e-3)
+    gx, gy, o_gx, o_gy = _check_simple_pass(ft, dev, oracle, "c5_B1_T8000_S1000_C512_r10", d, tol_f64=TOL_F64)
+    _check_pruned_pass(ft, dev, oracle, "c5_B1_T8000_S1000_C512_r10", d, 10, o_gx, o_gy, tol_f64=TOL_F64)
 
 
 def test_c5_full_size_pipeline_properties(ft, dev):
@@ -191,9 +217,10 @@ def test_c5_full_size_pipeline_properties(ft, dev):
 
 @pytest.mark.parametrize("shape", [(2, 50, 200), (2, 100, 512), (2, 200, 1000), (1, 400, 3000)])
 def test_recursion_accuracy_vs_float64(ft, dev, oracle, shape):
-    """The recursion alone on random lattices with realistic magnitudes (log-probs ~ N(-6,1)) against the float64 oracle:
-    the default (bidirectional) family must be at least as accurate as the reference's float32 arithmetic (float32
-    oracle; the `plain` family runs the same arithmetic on the device)."""
+    """The recursion alone on random lattices with realistic magnitudes (log-probs ~ N(-6,1), independent per cell: the
+    hardest case for float32, nothing telescopes along a path) against the float64 oracle: occupancies within 1e-4
+    normwise up to T = 1000 and 2e-4 at T = 3000 (round 2, before the operand shift: 2.5e-4 and 1.5e-3; the reference's
+    own arithmetic: 2.3e-3 and 2.4e-2)."""
     from tf_fast_rnnt.mutual_information import mi_forward_backward
     B, S, T = shape
     rng = np.random.default_rng(S + T)
@@ -210,4 +237,4 @@ def test_recursion_accuracy_vs_float64(ft, dev, oracle, shape):
     ey = _record(key, "py_grad", gy.cpu().numpy(), gy32, gy64)
     np.testing.assert_allclose(ans.cpu().numpy(), a64, rtol=1e-4)
     for e in (ex, ey):
-        assert e["normwise_vs_f64"] <= max(1e-4, e["f32_oracle_normwise_vs_f64"]), (key, e)
+        assert e["normwise_vs_f64"] <= (1e-4 if T <= 1000 else 2e-4), (key, e)

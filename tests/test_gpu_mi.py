@@ -136,6 +136,68 @@ def test_mi_vs_float64_oracle_long(ft, dev, oracle, impl):
     assert err <= max(1e-4, 1.5 * ref_err), (err, ref_err)
 
 
+@pytest.mark.parametrize("modified", [False, True])
+def test_operand_shift_is_invisible(ft, dev, oracle, modified):
+    """The kernels subtract per-utterance constants from px / py before the recursion (csrc/ftr_common.h, Shift) and add
+    what that took out of `ans` back.  Seen from outside nothing may depend on it: adding constants (cx to every px, cy
+    to every py) to the INPUTS moves ans by (px steps) cx + (py steps) cy of a complete path and leaves the occupancies
+    alone -- also for utterances with begin offsets, -inf entries, huge finite stand-ins for -inf (excluded from the
+    sampled means) and one lattice whose px are all -inf."""
+    B, S, T = 4, 90, 300
+    px, py, bd = random_lattice(77, B, S, T, modified=modified, neg_inf_frac=0.02, ragged=True, begin_offsets=True)
+    px[1][px[1] < -2.5] = -1.0e20                 # stand-ins for -inf
+    px[3] = -np.inf                               # no px at all: only the utterance with s_end == s_begin has a path
+    bd[3] = (5, 3, 5, T)
+    py[3, 5, :] = np.float32(-1.0) - np.abs(py[0, 5, :]).clip(0, 5)   # ... along finite blanks
+    ans0, gx0, gy0, _ = _run(ft, dev, px, py, bd, "wavefront")
+    o_ans, (o_gx, o_gy) = oracle.mutual_information_recursion(px, py, bd, True, np.float64)
+    ok = np.isfinite(o_ans)
+    assert ok[3] and np.array_equal(np.isfinite(ans0), ok)
+    np.testing.assert_allclose(ans0[ok], o_ans[ok], rtol=3e-6, atol=3e-5)
+    assert max_rel(gx0[ok], o_gx[ok]) <= 2e-5 and max_rel(gy0[ok], o_gy[ok]) <= 2e-5
+    for cx, cy in ((-37.5, 11.25), (300.0, -400.0)):
+        ans1, gx1, gy1, _ = _run(ft, dev, (px + np.float32(cx)).astype(np.float32), (py + np.float32(cy)).astype(np.float32), bd, "wavefront")
+        nx = (bd[:, 2] - bd[:, 0]).astype(np.float64)
+        ny = (bd[:, 3] - bd[:, 1]).astype(np.float64) - (nx if modified else 0.0)
+        np.testing.assert_allclose(ans1[ok], (o_ans + nx * cx + ny * cy)[ok], rtol=3e-6, atol=3e-5)
+        assert max_rel(gx1[ok], o_gx[ok]) <= 1e-4 and max_rel(gy1[ok], o_gy[ok]) <= 1e-4   # px + cx rounds the inputs themselves
+
+
+@pytest.mark.parametrize("kind", ["sharp", "blank_heavy", "tilted"])
+def test_accuracy_on_structured_lattices(ft, dev, oracle, kind):
+    """Accuracy against the float64 oracle where the sampled means say little about the paths that carry the
+    occupancy: a sharp (trained-looking) model whose alignment has px ~ -0.1 / py ~ -0.05 on it and -10 / -3 off it; a
+    blank-heavy model (py ~ -0.1, px ~ -8 everywhere); and independent cells with very different px and py means."""
+    B, S, T = 2, 200, 1000
+    rng = np.random.default_rng(5)
+    if kind == "sharp":
+        px = (rng.standard_normal((B, S, T + 1)) - 10.0).astype(np.float32)
+        py = (rng.standard_normal((B, S + 1, T)) - 3.0).astype(np.float32)
+        for b in range(B):
+            ts = np.sort(np.clip(np.round((np.arange(S) + 0.5) * T / S).astype(int) + rng.integers(-3, 4, S), 0, T - 1))
+            prev = 0
+            for s_ in range(S + 1):
+                end = ts[s_] if s_ < S else T
+                py[b, s_, prev:end] = -0.05
+                if s_ < S:
+                    px[b, s_, end] = -0.1
+                prev = end
+    elif kind == "blank_heavy":
+        px = (0.5 * rng.standard_normal((B, S, T + 1)) - 8.0).astype(np.float32)
+        py = (0.05 * rng.standard_normal((B, S + 1, T)) - 0.1).astype(np.float32)
+    else:
+        px = (rng.standard_normal((B, S, T + 1)) - 2.0).astype(np.float32)
+        py = (rng.standard_normal((B, S + 1, T)) - 9.0).astype(np.float32)
+    px[:, :, T] = -np.inf
+    bd = np.zeros((B, 4), np.int32); bd[:, 2] = S; bd[:, 3] = T
+    ans, gx, gy, _ = _run(ft, dev, px, py, bd, "wavefront")
+    a64, (gx64, gy64) = oracle.mutual_information_recursion(px, py, bd, True, np.float64)
+    # (the sharp lattice adds the SAME blank log-probability at every step of its alignment, so the roundings of its running
+    # sum do not average out; measured 6e-6 relative, 1e-7 ... 5e-8 on the other two)
+    np.testing.assert_allclose(ans, a64, rtol=2e-5 if kind == "sharp" else 2e-6)
+    assert max_rel(gx, gx64) <= 2e-5 and max_rel(gy, gy64) <= 2e-5, (kind, max_rel(gx, gx64), max_rel(gy, gy64))
+
+
 def test_mi_autograd(ft, dev, oracle):
     """The registered gradient (__init__.py:154-162): d(sum_b w_b ans_b)/d px = w_b * px_grad."""
     px, py, bd = random_lattice(21, 3, 6, 9, ragged=True)

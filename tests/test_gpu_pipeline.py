@@ -334,7 +334,12 @@ def test_smoothed_loss_against_oracle(ft, dev, oracle):
         want, (ox, oy) = oracle.rnnt_loss_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"], 0.1, 0.2,
                                                    d["boundary"], rt, 0.2, "none", True)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4)
-        assert max_rel(gx.cpu().numpy(), ox) <= 5e-4 and max_rel(gy.cpu().numpy(), oy) <= 5e-4
+        # occupancies against the float64 recursion on the oracle's float32 px / py (the float32 recursion is 3e-4 off at T=200)
+        opx, opy = oracle.get_rnnt_logprobs_smoothed(d["lm"], d["am"], d["symbols"], d["termination_symbol"], 0.1, 0.2, d["boundary"], rt)
+        opx = oracle._delay_penalty(opx, d["boundary"], rt, 0.2)
+        _, (ox64, oy64) = oracle.mutual_information_recursion(opx, opy, d["boundary"], True, np.float64)
+        assert max_rel(gx.cpu().numpy(), ox64) <= 2e-5 and max_rel(gy.cpu().numpy(), oy64) <= 2e-5
+        assert max_rel(gx.cpu().numpy(), ox) <= 1.05 * max_rel(ox, ox64) + 2e-5 and max_rel(gy.cpu().numpy(), oy) <= 1.05 * max_rel(oy, oy64) + 2e-5
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified", "constrained"])
@@ -554,23 +559,29 @@ def test_out_of_range_caller_data_does_not_fault(ft, dev):
 def test_against_committed_golden_fixtures(ft, dev, name):
     """The HIP path against the committed fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the
     oracle; the reference holds no expected values of its own): every stage of the pipeline on the fixture's inputs.
-    Ranges bit-exact given the fixture's occupancies; losses 1e-4 elementwise; lattices and gradients 1e-4 normwise
-    (5e-4 for the T=200 fixture, where float32 log-domain noise of the oracle itself is 3e-4)."""
+    Ranges bit-exact given the fixture's occupancies; losses 1e-4 elementwise; occupancies and gradients 2e-5 normwise
+    against the fixture's *_f64 arrays (the same float32 px / py through the recursion in float64; measured 1e-6 ... 8e-6),
+    and against the float32 arrays (the reference's arithmetic) within that arithmetic's own distance from the float64
+    arrays, which is 3e-4 at T=200."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     blank = int(g["termination_symbol"])
     am, lm, sym, bd = (_t(g[k], dev) for k in ("am", "lm", "symbols", "boundary"))
-    tol = 5e-4 if name.startswith("seed12345") else 1e-4
+
+    def close(got, key):
+        got = got.cpu().numpy()
+        assert max_rel(got, g[key + "_f64"]) <= 2e-5, (name, key, max_rel(got, g[key + "_f64"]))
+        assert max_rel(got, g[key]) <= max(1e-5, 1.05 * max_rel(g[key], g[key + "_f64"])) + 2e-5, (name, key)
     px, py = ft.get_rnnt_logprobs(lm, am, sym, blank, "regular", bd)
     assert np.array_equal(np.isneginf(px.cpu().numpy()), np.isneginf(g["simple_px"]))
     assert max_rel(px.cpu().numpy(), g["simple_px"]) <= 1e-5 and max_rel(py.cpu().numpy(), g["simple_py"]) <= 1e-5
     loss, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, reduction="none", calc_gradients=True)
     np.testing.assert_allclose(loss.cpu().numpy(), g["simple_loss"], rtol=1e-4)
-    assert max_rel(gx.cpu().numpy(), g["simple_px_grad"]) <= tol and max_rel(gy.cpu().numpy(), g["simple_py_grad"]) <= tol
+    close(gx, "simple_px_grad"); close(gy, "simple_py_grad")
     sl, (sgx, sgy) = ft.rnnt_loss_smoothed(lm, am, sym, blank, lm_only_scale=0.1, am_only_scale=0.2, boundary=bd,
                                            reduction="none", delay_penalty=0.2, calc_gradients=True)
     np.testing.assert_allclose(sl.cpu().numpy(), g["smoothed_loss"], rtol=1e-4)
-    assert max_rel(sgx.cpu().numpy(), g["smoothed_px_grad"]) <= tol and max_rel(sgy.cpu().numpy(), g["smoothed_py_grad"]) <= tol
+    close(sgx, "smoothed_px_grad"); close(sgy, "smoothed_py_grad")
     for r in [int(v) for v in g["s_ranges"]]:
         want = g[f"ranges_r{r}"]
         got = ft.get_rnnt_prune_ranges(_t(g["smoothed_px_grad"], dev), _t(g["smoothed_py_grad"], dev), bd, r)
@@ -580,7 +591,7 @@ def test_against_committed_golden_fixtures(ft, dev, name):
         pl = ft.rnnt_loss_pruned(logits, sym, _t(want, dev), blank, bd, delay_penalty=0.2, reduction="mean")
         pl.backward()
         np.testing.assert_allclose(pl.item(), float(g[f"pruned_loss_r{r}"]), rtol=1e-4)
-        assert max_rel(logits.grad.cpu().numpy(), g[f"pruned_logits_grad_r{r}"]) <= tol
+        close(logits.grad, f"pruned_logits_grad_r{r}")
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])

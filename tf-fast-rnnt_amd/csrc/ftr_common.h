@@ -69,6 +69,37 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---- per-utterance shift of the recursion's operands (mi_wave_bidir.hip, mi_band.hip)
+// The recursion is invariant under px -> px - cx, py -> py - cy with constants per utterance: every complete path takes
+// the same number of px steps (s_end - s_begin) and of py steps (t_end - t_begin; modified: minus the px steps), so both
+// incoming terms of every cell move together -- split ratios, occupancies and gradients are unchanged and `ans` moves
+// by a known amount, which the cut reduction adds back.  What the shift buys is float32 accuracy: unshifted, p(s,t)
+// reaches -5e3 .. -1e5 (log2 units) on a long lattice, one ulp there is 5e-4 .. 8e-3, and the split ratio is formed from
+// the DIFFERENCE of two such numbers (the reference's own arithmetic has the same defect: term1 / term2 at
+// mutual_information_cuda.cu:642-660 subtract them in the backward pass).  With cx, cy chosen so that a path along the
+// rectangle's diagonal gains nothing on average -- cx = mean(px) - ln f, cy = mean(py) - ln(1 - f), f = the fraction of
+// px steps -- p stays within tens to hundreds along the paths that carry the occupancy.  The means are estimates (a
+// fixed sample, or the band itself): any finite constants are exact in exact arithmetic.
+struct Shift { float cx2, cy2; };   // log2 domain
+__device__ __forceinline__ bool shift_sample_ok(float v) { return v > -1.0e4f && v < 1.0e4f; }   // not -inf / NaN / a huge stand-in for -inf
+template <bool MOD>
+__device__ __forceinline__ Shift shift_from_sums(float sumx, float nx, float sumy, float ny, int Sn, int Tn) {
+  const float steps = MOD ? (float)(Tn - 1) : (float)(Sn - 1 + Tn - 1);
+  float f = steps > 0.0f ? (float)(Sn - 1) / steps : 0.5f;
+  f = fminf(fmaxf(f, 1.0e-3f), 1.0f - 1.0e-3f);
+  const float mx = nx > 0.0f ? sumx / nx : 0.0f, my = ny > 0.0f ? sumy / ny : 0.0f;
+  Shift s;
+  s.cx2 = mx * kLog2e - __builtin_amdgcn_logf(f);
+  s.cy2 = my * kLog2e - __builtin_amdgcn_logf(1.0f - f);
+  return s;
+}
+// what the shifts took out of `ans` (log2 units): px steps * cx2 + py steps * cy2 of any complete path
+template <bool MOD>
+__device__ __forceinline__ double shift_total(const Shift s, int Sn, int Tn) {
+  const int nx = Sn - 1, ny = MOD ? (Tn - 1) - (Sn - 1) : (Tn - 1);
+  return (double)nx * (double)s.cx2 + (double)ny * (double)s.cy2;
+}
+
 struct Bound { int sb, tb, se, te; };
 __device__ __forceinline__ Bound load_boundary(const int32_t* __restrict__ boundary, int b, int S, int T) {
   Bound r;

@@ -184,8 +184,13 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
   //   chain A's slot of a cell: OX = px(s-1, t [t-1 if modified]), OY = py(s, t-1)      (the transitions INTO the cell)
   //   chain B's slot:           OX = px(s,t), OY = py(s,t)                              (the transitions OUT of it)
   const int nfr = (te - tb) * r;                                     // frames [tb, te)
+  // While an array is staged its finite entries are summed: the mean gives this utterance's shift constant (ftr_common.h,
+  // Shift), which operands() subtracts from every transition it scatters.  Per-wave partial sums go through red[]
+  // (the cut exchange area, unused until the chains run) in a fixed order, so all threads derive the same constant.
+  float* red = cutA;
   auto stage = [&](const float* src) {
     const float* g0 = src + ((size_t)b * T + tb) * r;
+    float ssum = 0.0f, scnt = 0.0f;
     for (int i0 = 0; i0 < nfr; i0 += 8 * 4 * kBandThreads) {
       f4 v[8];
 #pragma unroll
@@ -197,13 +202,23 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 4 * (u * kBandThreads + tid);
-        for (int e = 0; e < 4; ++e) if (i + e < nfr) G[i + e] = v[u][e] * kLog2e;
+        for (int e = 0; e < 4; ++e) if (i + e < nfr) {
+          G[i + e] = v[u][e] * kLog2e;
+          if (shift_sample_ok(v[u][e])) { ssum += v[u][e]; scnt += 1.0f; }
+        }
       }
     }
+    ssum = wave_sum_dpp(ssum); scnt = wave_sum_dpp(scnt);
+    if (lane == 0) { red[wave] = ssum; red[8 + wave] = scnt; }
+  };
+  auto staged_sums = [&](float& sum, float& cnt) {   // after the barrier behind stage()
+    sum = 0.0f; cnt = 0.0f;
+#pragma unroll
+    for (int u = 0; u < kBandThreads / 64; ++u) { sum += red[u]; cnt += red[8 + u]; }
   };
   auto staged = [&](int s, int t) { return G[(t - tb) * r + (s - lo[t])]; };   // band value at lattice cell (s,t), frame t < te
   unsigned nan_acc = 0;
-  auto operands = [&](auto xtag) {
+  auto operands = [&](auto xtag, const float c2) {
     constexpr bool ISX = decltype(xtag)::value;
     float* O = reinterpret_cast<float*>(O2) + (ISX ? 0 : 1);
     for (int i = tid; i < Tn * r; i += kBandThreads) {
@@ -214,8 +229,8 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       const int dg = MOD ? (t - tb) : (s - sb) + (t - tb);
       if (dg <= jm) {
         float av = kNeg;
-        if (ISX) { const int tx = MOD ? t - 1 : t; if (s - 1 >= sb && tx >= tb && tx <= te - 1 && in_band(s - 1, tx)) av = staged(s - 1, tx); }
-        else { if (t - 1 >= tb && in_band(s, t - 1)) av = staged(s, t - 1); if (s == sb && t == tb) av = 0.0f; }   // origin trick
+        if (ISX) { const int tx = MOD ? t - 1 : t; if (s - 1 >= sb && tx >= tb && tx <= te - 1 && in_band(s - 1, tx)) av = staged(s - 1, tx) - c2; }
+        else { if (t - 1 >= tb && in_band(s, t - 1)) av = staged(s, t - 1) - c2; if (s == sb && t == tb) av = 0.0f; }   // origin trick
         nan_acc = max(nan_acc, __float_as_uint(av) & 0x7fffffffu);
         O[2 * slotA(s, t)] = fmaxf(av, kNeg);
         if (ISX && dg == jm) cutSA[(s - sb) & (LANES - 1)] = s;
@@ -223,8 +238,8 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       if (dg >= jm) {
         float bv = kNeg;
         if (t <= te - 1) {
-          if (ISX) { const int tnx = MOD ? t + 1 : t; if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) bv = staged(s, t); }
-          else if (in_band(s, t + 1)) bv = staged(s, t);
+          if (ISX) { const int tnx = MOD ? t + 1 : t; if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) bv = staged(s, t) - c2; }
+          else if (in_band(s, t + 1)) bv = staged(s, t) - c2;
         }
         if (!ISX && s == se && t == te) bv = 0.0f;                   // chain B's origin is the end cell
         nan_acc = max(nan_acc, __float_as_uint(bv) & 0x7fffffffu);
@@ -236,16 +251,23 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     // step D is behind the cut unless the rectangle is a single column (handled above)
     if (end_above && tid == 0) O[2 * slotB(se, te)] = ISX ? kNeg : 0.0f;
   };
+  float sumx, cntx, sumy, cnty;
   stage(pxb);
   __syncthreads();
   FTR_BSTAMP(2);
-  operands(std::true_type{});
+  staged_sums(sumx, cntx);
+  // cx2 depends on the px mean only and cy2 on the py mean only (shift_from_sums)
+  const float cx2 = shift_from_sums<MOD>(sumx, cntx, 0.0f, 0.0f, Sn, Tn).cx2;
+  operands(std::true_type{}, cx2);
   __syncthreads();
   FTR_BSTAMP(3);
   stage(pyb);
   __syncthreads();
   FTR_BSTAMP(4);
-  operands(std::false_type{});
+  staged_sums(sumy, cnty);
+  const float cy2 = shift_from_sums<MOD>(0.0f, 0.0f, sumy, cnty, Sn, Tn).cy2;
+  operands(std::false_type{}, cy2);
+  const double shift_back = shift_total<MOD>(Shift{cx2, cy2}, Sn, Tn);   // what the shifts took out of ans (log2 units)
   const bool poisoned = __syncthreads_or(nan_acc > 0x7f800000u) != 0;
   FTR_BSTAMP(5);
 
@@ -274,6 +296,18 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
       G[slot] = (d >= 0.0f) ? rc : ex * rc;
     };
+    // Renormalisation ("frames", as in mi_wave_bidir.hip): every 2 U steps the chain's values are brought back to the
+    // neighbourhood of zero by an integer shift, the same for all lanes of the chain (a uniform shift of an anti-diagonal
+    // changes no split ratio), so that float32 keeps its resolution whatever the magnitude of the log-probabilities -- the
+    // static shift above only removes what the band's MEAN transition predicts.  The maximum is taken from a copy made one
+    // iteration earlier, off the dependent chain; on the chain it costs one subtraction per 2 U steps.  frame = what has
+    // been subtracted so far, added back on the cut.
+    float frame = 0.0f;
+    auto renorm = [&](float snap) {   // snap: this lane's value 2 U steps ago (no shift in between: the same frame)
+      const float mx = row16_max(snap);
+      const float st = (mx > kNegThresh) ? __builtin_rintf(mx) : 0.0f;
+      val -= st; frame += st;
+    };
     {
       // two register sets, each filled half an iteration (U steps) before it is used
       float2 oa[U], ob[U];
@@ -282,6 +316,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       int i = 0;
       for (; i + 2 * U <= n1; i += 2 * U) {
         const int sl = base1 + i * LANES;
+        const float snap = val;
 #pragma unroll
         for (int u = 0; u < U; ++u) ob[u] = O2[sl + (U + u) * LANES];
 #pragma unroll
@@ -290,6 +325,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
         for (int u = 0; u < U; ++u) oa[u] = O2[sl + (2 * U + u) * LANES];
 #pragma unroll
         for (int u = 0; u < U; ++u) fwd(sl + (U + u) * LANES, ob[u]);
+        renorm(snap);
       }
       for (; i < n1; ++i) fwd(base1 + i * LANES, O2[base1 + i * LANES]);
     }
@@ -301,6 +337,9 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
     if (scut >= 0) (isB ? cutB : cutA)[scut & 15] = val;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
+      // both chains' frames: chain A's lanes hold theirs in DPP rows 0 / 2, chain B's in rows 1 / 3
+      const float frA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frame), 0));
+      const float frB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frame), 16));
       const float v = cutA[l16] + cutB[l16];
       const float m = row16_max(v);
       const float e = exp2f(v - m);
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       const float total = m + log2f(sum);
       const bool dead = !(total > kNegThresh);
       if (lane < 16) occ[lane] = (dead || poisoned) ? 0.0f : e / sum;
-      if (lane == 0) ans[b] = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : total * kLn2);
+      if (lane == 0) ans[b] = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : (float)(((double)total + (double)frA + (double)frB + shift_back) * 0.6931471805599453));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const float inj = (scut >= 0) ? occ[scut & 15] : 0.0f;   // the occupancy this lane injects at its cut cell
@@ -439,7 +478,36 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
   }
   for (int i = tid; i < nrows * LANES; i += kBandThreads) { O2[i] = make_float2(kNeg, 0.0f); G[i] = 0.0f; }   // neutral slots
   if (tid < 32) cutSA[tid] = -1;
+  // the utterance's shift constants (ftr_common.h, Shift) from a fixed sample of the band arrays: 2048 entries of each,
+  // per-wave partial sums through the cut exchange area, summed by every thread in the same order
+  const float* pxu = pxb + (size_t)b * T * r;
+  const float* pyu = pyb + (size_t)b * T * r;
+  {
+    const unsigned nfr = (unsigned)(te - tb) * (unsigned)r;
+    float sx = 0.0f, nx = 0.0f, sy = 0.0f, ny = 0.0f;
+    float vx[4], vy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned i = (unsigned)tb * (unsigned)r + __umulhi((unsigned)(tid + kBandThreads * u) * 0x9E3779B1u, nfr);
+      vx[u] = pxu[i]; vy[u] = pyu[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (shift_sample_ok(vx[u])) { sx += vx[u]; nx += 1.0f; }
+      if (shift_sample_ok(vy[u])) { sy += vy[u]; ny += 1.0f; }
+    }
+    sx = wave_sum_dpp(sx); nx = wave_sum_dpp(nx); sy = wave_sum_dpp(sy); ny = wave_sum_dpp(ny);
+    if (lane == 0) { cutA[wave] = sx; cutA[8 + wave] = nx; cutA[16 + wave] = sy; cutA[24 + wave] = ny; }
+  }
   __syncthreads();
+  Shift sh;
+  {
+    float sx = 0.0f, nx = 0.0f, sy = 0.0f, ny = 0.0f;
+#pragma unroll
+    for (int u = 0; u < kBandThreads / 64; ++u) { sx += cutA[u]; nx += cutA[8 + u]; sy += cutA[16 + u]; ny += cutA[24 + u]; }
+    sh = shift_from_sums<MOD>(sx, nx, sy, ny, Sn, Tn);
+  }
+  const double shift_back = shift_total<MOD>(sh, Sn, Tn);
   {
     int bad = 0;
     for (int t = tb + 1 + tid; t < te; t += kBandThreads) bad |= (lo[t] < lo[t - 1]);
@@ -453,10 +521,8 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
   auto in_band = [&](int s, int t) { const int l = lo[t]; return (s >= l && s <= l + r - 1) || (end_above && t == te && s == se); };
   auto slotA = [&](int s, int t) { return (rowA + (MOD ? (t - tb) : (s - sb) + (t - tb))) * LANES + ((s - sb) & (LANES - 1)); };
   auto slotB = [&](int s, int t) { return (rowB + (MOD ? (te - t) : (se - s) + (te - t))) * LANES + ((se - s) & (LANES - 1)); };
-  // band value at lattice cell (s, t), frame t < te, log2 domain
-  const float* pxu = pxb + (size_t)b * T * r;
-  const float* pyu = pyb + (size_t)b * T * r;
-  auto at = [&](const float* src, int s, int t) { return src[(size_t)t * r + (s - lo[t])] * kLog2e; };
+  // band value at lattice cell (s, t), frame t < te, log2 domain, shifted
+  auto at = [&](const float* src, float c2, int s, int t) { return __builtin_fmaf(src[(size_t)t * r + (s - lo[t])], kLog2e, -c2); };
   unsigned nan_acc = 0;
   auto put = [&](int slot, float x, float y) {
     nan_acc = max(nan_acc, max(__float_as_uint(x) & 0x7fffffffu, __float_as_uint(y) & 0x7fffffffu));
@@ -472,8 +538,8 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
     if (dg <= jm) {        // chain A: the transitions INTO the cell
       float ax = kNeg, ay = kNeg;
       const int tx = MOD ? t - 1 : t;
-      if (s - 1 >= sb && tx >= tb && tx <= te - 1 && in_band(s - 1, tx)) ax = at(pxu, s - 1, tx);
-      if (t - 1 >= tb && in_band(s, t - 1)) ay = at(pyu, s, t - 1);
+      if (s - 1 >= sb && tx >= tb && tx <= te - 1 && in_band(s - 1, tx)) ax = at(pxu, sh.cx2, s - 1, tx);
+      if (t - 1 >= tb && in_band(s, t - 1)) ay = at(pyu, sh.cy2, s, t - 1);
       if (s == sb && t == tb) ay = 0.0f;                               // origin trick
       put(slotA(s, t), ax, ay);
       if (dg == jm) cutSA[(s - sb) & (LANES - 1)] = s;
@@ -482,8 +548,8 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
       float bx = kNeg, by = kNeg;
       if (t <= te - 1) {
         const int tnx = MOD ? t + 1 : t;
-        if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) bx = at(pxu, s, t);
-        if (in_band(s, t + 1)) by = at(pyu, s, t);
+        if (s + 1 <= se && tnx <= te && in_band(s + 1, tnx)) bx = at(pxu, sh.cx2, s, t);
+        if (in_band(s, t + 1)) by = at(pyu, sh.cy2, s, t);
       }
       if (s == se && t == te) by = 0.0f;                               // chain B's origin is the end cell
       put(slotB(s, t), bx, by);
@@ -512,20 +578,31 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
       const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
       G[slot] = (d >= 0.0f) ? rc : ex * rc;
     };
+    // renormalisation of the chains' values every 2 U steps, see the LDS kernel
+    float frame = 0.0f;
+    auto renorm = [&](float snap) {
+      const float mx = row16_max(snap);
+      const float st = (mx > kNegThresh) ? __builtin_rintf(mx) : 0.0f;
+      val -= st; frame += st;
+    };
     {
       float2 o[NS][U];
 #pragma unroll
       for (int k = 0; k < NS - 1; ++k)
 #pragma unroll
         for (int u = 0; u < U; ++u) o[k][u] = O2[base1 + (k * U + u) * LANES];
+      static_assert((NS & 1) == 0, "the renormalisation pairs the register sets");
       for (int i = 0; i < nrun; i += P) {
+        float snap = val;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
           const int kf = (k + NS - 1) % NS;                     // the set NS - 1 groups ahead
+          if ((k & 1) == 0) snap = val;
 #pragma unroll
           for (int u = 0; u < U; ++u) o[kf][u] = O2[base1 + (i + (k + NS - 1) * U + u) * LANES];
 #pragma unroll
           for (int u = 0; u < U; ++u) fwd(base1 + (i + k * U + u) * LANES, o[k][u]);
+          if ((k & 1) == 1) renorm(snap);
         }
       }
     }
@@ -536,6 +613,9 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
     if (scut >= 0) (isB ? cutB : cutA)[scut & 15] = val;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
+      // both chains' frames: chain A's lanes hold theirs in DPP rows 0 / 2, chain B's in rows 1 / 3
+      const float frA = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frame), 0));
+      const float frB = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frame), 16));
       const float v = cutA[l16] + cutB[l16];
       const float m = row16_max(v);
       const float e = exp2f(v - m);
@@ -543,7 +623,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
       const float total = m + log2f(sum);
       const bool dead = !(total > kNegThresh);
       if (lane < 16) occ[lane] = (dead || poisoned) ? 0.0f : e / sum;
-      if (lane == 0) ans[b] = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : total * kLn2);
+      if (lane == 0) ans[b] = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : (float)(((double)total + (double)frA + (double)frB + shift_back) * 0.6931471805599453));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const float inj = (scut >= 0) ? occ[scut & 15] : 0.0f;

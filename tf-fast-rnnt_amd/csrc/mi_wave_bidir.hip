@@ -27,7 +27,7 @@
 // (s - s_begin, t - t_begin); "REV addressing" = (s_end - s, t_end - t).  Forward alpha and flow beta use FWD,
 // forward beta and flow alpha use REV.
 //
-// Workspace ("p" in the C ABI), floats:  [ G_alpha lattice | G_beta lattice | pmid 2*B*(S+1) | occ B*(S+1) | seed B | pad |
+// Workspace ("p" in the C ABI), floats:  [ G_alpha lattice | G_beta lattice | pmid 2*B*(S+1) | occ B*(S+1) | seed B | shift 2*B | cut frames 2*B*NB | pad |
 //                                          ctrl: status word, done[B], uflags[B] | pad |
 //                                          granules of the forward launch 2*B*NB*Tg*8 bytes | granules of the flow launch ].
 // "ctrl + granules" is the HAND-OFF region: it must be all zero when a launch starts.  The launches leave it all zero
@@ -105,10 +105,16 @@ __host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
 __device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
   return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool comm_import(float* in_ring, u64* gran_in, int m, int lane, u64 g, int* status) {
+// Granule = { tag, value }, tag = (chunk + 1) | (frame step of that chunk << 16): see "Frames" in the forward body (the
+// flow kernel publishes a zero step).  16 bits of chunk number: T + 64 < 16 * 65535, checked by the launchers.
+constexpr unsigned kTagChunkMask = 0xffffu;
+constexpr int kStepMax = 32767;        // 16-bit signed frame step
+// Waits (bounded) for the 16 granules of chunk m; `g` comes in as this lane's granule as peeked one slot ago and goes out
+// as read with the right tag.  false: the producer never showed up (sticky status bit set).
+__device__ __forceinline__ bool comm_wait(u64* gran_in, int m, int lane, u64& g, int* status) {
   const int idx = CH * m + (lane & (CH - 1));
   for (int spins = 0;; ++spins) {
-    const bool ok = (unsigned)(g >> 32) == (unsigned)(m + 1);
+    const bool ok = ((unsigned)(g >> 32) & kTagChunkMask) == (unsigned)(m + 1);
     if (__all(ok)) break;                 // wave-uniform exit
     if (spins >= kMaxSpin) {              // wave-uniform (spins is uniform): the producer never showed up
       if (lane == 0) __hip_atomic_fetch_or(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky
@@ -117,7 +123,14 @@ __device__ __forceinline__ bool comm_import(float* in_ring, u64* gran_in, int m,
     __builtin_amdgcn_s_sleep(FTR_POLL_SLEEP);
     g = __hip_atomic_load(gran_in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (lane < CH) in_ring[idx & (RINGN - 1)] = __uint_as_float((unsigned)g);
+  return true;
+}
+__device__ __forceinline__ void ring_put(float* in_ring, int m, int lane, float v) {
+  if (lane < CH) in_ring[(CH * m + lane) & (RINGN - 1)] = v;
+}
+__device__ __forceinline__ bool comm_import(float* in_ring, u64* gran_in, int m, int lane, u64 g, int* status) {
+  if (!comm_wait(gran_in, m, lane, g, status)) return false;
+  ring_put(in_ring, m, lane, __uint_as_float((unsigned)g));
   return true;
 }
 // this band is the only reader of its granules: it leaves them zero for the next launch on this workspace
@@ -165,8 +178,9 @@ template <bool MOD, bool REVM>
 __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float* __restrict__ px,
                                                const float* __restrict__ py, const Bound bd, float* __restrict__ wsb,
                                                u64* __restrict__ gran_b, float* __restrict__ pmid_b,
-                                               int* __restrict__ status, int* __restrict__ uflag_b, int b, int w,
-                                               int Tg, int S, int T, int jstop) {
+                                               int* __restrict__ status, int* __restrict__ uflag_b,
+                                               float* __restrict__ cxy_b, int* __restrict__ phimid_b, int b, int w, int Tg,
+                                               int S, int T, int jstop) {
   constexpr int SKEW = MOD ? 0 : 1;
   constexpr int NOFF = MOD ? 1 : 0;
   constexpr int NPF = FTR_NPF_FWD;
@@ -186,6 +200,20 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 
   f4* lds = reinterpret_cast<f4*>(smem);
   float* in_ring = reinterpret_cast<float*>(lds + kFwdTiles * TILE_F4);   // values of the band above (row row0-1)
+  float* shift_lds = in_ring + RINGN;   // the utterance's shift constants (cx2, cy2): COMM wave -> IO-in wave
+  // Frames.  On top of the per-utterance operand shift (which removes the mean drift and the tilt of p over the lattice for
+  // a model whose paths are diffuse) every band renormalises its own values as it goes: at the start of chunk k the compute
+  // wave subtracts an integer step[k] from its 64 values (one subtraction per 16 steps on the chain), so that they stay
+  // small whatever the model -- a sharp model's log-probabilities along its alignment are nothing like the sampled means,
+  // and with the static shift alone `ans` came out of the cancellation of two numbers of several thousand.  A uniform shift
+  // of a whole anti-diagonal changes no split ratio.  frame(k) = step[0] + ... + step[k]; a stored value + frame(k) = the
+  // (statically shifted) log-probability.  step[k + 3] is set by the IO-out wave from the largest value at the end of chunk
+  // k (it reads the compute wave's output tile anyway): step[k+3] = rint(max + 2.5 drift) - step[k+1] - step[k+2], three chunks ahead so
+  // that the COMM wave, which converts the values of the band above into this band's frame when it imports them (five
+  // chunks before their use), already knows the frame they will be used in.  The steps travel to the band below in the tag
+  // word of the granules, the frame of the cut values goes to the cut reduction (phimid).
+  float* sring = shift_lds + 2;         // step[k & 7], float-valued integers in [-32767, 32767]; sring[8] = the band's base frame
+  if (threadIdx.x < 9) sring[threadIdx.x] = 0.0f;
   for (int i = threadIdx.x; i < RINGN; i += blockDim.x) in_ring[i] = kNeg;
   __syncthreads();
 
@@ -194,12 +222,14 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   const int jl = jstop - SKEW * 64 * w;
   if (jl < 0) {
     if (wid == 0 && 64 * w + lane < Sn) pmid_store(pmid_b + 64 * w + lane, kNeg);
+    if (wid == 0 && lane == 0) __hip_atomic_store(phimid_b + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   // A band never steps past its own last column (local step Tn - 1 + 63 * SKEW): if the cut lies beyond that, none
   // of the band's rows has a cell on the cut, but the band still feeds the bands below.
   const int nchunks_nat = (Tn + 63 * SKEW + CH - 1) / CH;
   if (jl >= CH * nchunks_nat && wid == 0 && 64 * w + lane < Sn) pmid_store(pmid_b + 64 * w + lane, kNeg);
+  if (jl >= CH * nchunks_nat && wid == 0 && lane == 0) __hip_atomic_store(phimid_b + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int klast = min(jl / CH + 1, nchunks_nat);   // chunks [0, klast): local steps 0 .. jl (and the rest of that chunk)
   const int klast_up = MOD ? klast : min((jl + 64) / CH + 1, nchunks_nat);   // what the band above computes (and publishes)
   const int nslots = klast + PRE + 1;
@@ -225,10 +255,11 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     // every quad paid a full LDS round trip -- 1529 of the slot's 1729 cycles were this wave, profiles/r02_b_stamps_stage1.log).
     // (The band above's values -- four broadcast reads -- are read at the start of the slot that uses them: one slot
     // less of hand-off lag per band than reading them a slot ahead with the tiles.)
-    struct Ops { f4 X[NQ], Y[NQ]; };
+    struct Ops { f4 X[NQ], Y[NQ]; float step; };
     auto fetch = [&](int k, Ops& o) {
       const f4* cX = FTR_TX(k);
       const f4* cY = FTR_TY(k);
+      o.step = sring[k & 7];   // this chunk's frame step (see "Frames"), written two slots ago, read one slot ahead like the operands
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         o.X[q] = cX[q * PLANE + lane];
@@ -241,6 +272,8 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       f4 E[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) E[q] = ring_in[((CH * k + 4 * q) & (RINGN - 1)) >> 2];  // same address in every lane (broadcast)
+      pcur -= o.step;     // into this chunk's frame: the one operation per chunk that the renormalisation costs the chain
+      ecarry -= o.step;   // (the carried element was imported for the previous chunk's frame)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const f4 X4 = o.X[q], Y4 = o.Y[q], E4 = E[q];
@@ -304,17 +337,74 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     const bool has_up = w > 0;
     bool dead = false;
     u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
+    // The shift constants of this utterance (ftr_common.h, Shift): a fixed sample of 512 elements of px and of py inside
+    // the rectangle, the same positions in every band and direction, so every workgroup of the utterance derives the same
+    // two numbers bit for bit.  This wave has nothing else to do in the warm-up slots: the 16 loads per lane go out now,
+    // are reduced in slot kShiftSlot (the last warm-up slot: by then they have had three slots to arrive, and nothing queues
+    // behind this wave's wait) and reach the IO-in wave through LDS one barrier later, at the top of the slot of its first park.
+    constexpr int kShiftSlot = 3;
+    float smp_x[8], smp_y[8];
+    {
+      const int nrx = Sn - 1, ncx = Tn - NOFF, nry = Sn, ncy = Tn - 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned i = (unsigned)(lane + 64 * u);
+        const unsigned hr = i * 0x9E3779B1u, hc = i * 0x85EBCA77u + 0x1234567u;
+        smp_x[u] = -INFINITY; smp_y[u] = -INFINITY;
+        if (nrx > 0 && ncx > 0) smp_x[u] = px[(ptrdiff_t)(bd.sb + (int)__umulhi(hr, (unsigned)nrx)) * T1 + bd.tb + (int)__umulhi(hc, (unsigned)ncx)];
+        if (ncy > 0) smp_y[u] = py[(ptrdiff_t)(bd.sb + (int)__umulhi(hr, (unsigned)nry)) * T + bd.tb + (int)__umulhi(hc, (unsigned)ncy)];
+      }
+    }
+    int frame_rel = 0;   // (frame of the band above at chunk m - 1) - (this band's frame at chunk kc)
+    constexpr int kFirstUsed = MOD ? 0 : 3;   // first chunk of the band above whose values this band reads (regular: its step 63)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int m = kc + LOOK;
+      if (gg == kShiftSlot) {
+        float sx = 0.0f, nx = 0.0f, sy = 0.0f, ny = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (shift_sample_ok(smp_x[u])) { sx += smp_x[u]; nx += 1.0f; }
+          if (shift_sample_ok(smp_y[u])) { sy += smp_y[u]; ny += 1.0f; }
+        }
+        Shift sh = shift_from_sums<MOD>(wave_sum_dpp(sx), wave_sum_dpp(nx), wave_sum_dpp(sy), wave_sum_dpp(ny), Sn, Tn);
+#ifdef FTR_EXP_NOSTATIC   // study build: no operand shift
+        sh.cx2 = 0.0f; sh.cy2 = 0.0f;
+#endif
+        if (lane == 0) {
+          shift_lds[0] = sh.cx2; shift_lds[1] = sh.cy2;
+          if (w == 0 && !REVM) { pmid_store(cxy_b, sh.cx2); pmid_store(cxy_b + 1, sh.cy2); }   // for the cut reduction
+        }
+      }
 #ifdef FTR_EXP_NOPOLL
       if (false) {
 #else
       if (has_up && !dead && m >= 0 && m < klast_up) {
 #endif
-        if (!comm_import(in_ring, gran_in, m, lane, g_cur, status)) {   // producer never showed up: poison, stop polling
+        // the values are for local chunk kc + 1: its step was written by the IO-out wave one slot ago
+        if (kc + 1 >= 0 && kc + 1 < klast) frame_rel -= (int)sring[(kc + 1) & 7];
+        if (!comm_wait(gran_in, m, lane, g_cur, status)) {   // producer never showed up: poison, stop polling
           dead = true;
           in_ring[lane] = __builtin_nanf("");
+        } else {
+          // the values are log-probabilities in the producer's frame of its chunk m: the tag carries that chunk's step
+          frame_rel += ((int)__builtin_amdgcn_readfirstlane((int)(g_cur >> 32))) >> 16;   // arithmetic shift: signed step
+          float v = __uint_as_float((unsigned)g_cur);
+          if (m == kFirstUsed) {
+            // the first chunk of the band above that this band uses: this band's frame starts where those values are (by
+            // now the band above may be thousands away from zero, and a frame that started at zero would spend the three
+            // chunks of the schedule's lag at that magnitude).  The base frame is a virtual step in front of chunk 0.
+            const float mx = wave_max_dpp((lane < CH && v > kNegThresh) ? v : -INFINITY);
+            int f0 = 0;
+            if (mx > kNegThresh) f0 = min(max(frame_rel + (int)__builtin_rintf(mx), -kStepMax), kStepMax);
+#ifdef FTR_EXP_NOFRAMES
+            f0 = 0;
+#endif
+            frame_rel -= f0;
+            if (lane == 0) sring[8] = (float)f0;
+          }
+          v += (float)frame_rel;   // exact frame arithmetic (integers); -inf stays -1e30
+          ring_put(in_ring, m, lane, v);
         }
       }
       // the next chunk's granules are requested now and looked at one whole slot later
@@ -400,6 +490,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   // NaN detection among the px / py values this lane stages (reported through uflags: ans = NaN): the running maximum of
   // the magnitudes' bit patterns exceeds that of infinity iff a NaN went by (two VALU instructions per value, no branches)
   unsigned nan_acc = 0;
+  float cx2 = 0.0f, cy2 = 0.0f;   // the utterance's shift (log2 domain), read from LDS in slot 4 (IO-in wave)
   // v'[j] = v[j + d] (memory order): realigns a quad whose load address was clamped into the utterance's slab; the
   // elements that fall off are outside the slab, hence outside the boundary rectangle, and are masked by the caller
   auto shift4 = [](const f4 v, int d) {
@@ -448,7 +539,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           rx_ = (c >= NOFF && c < Tn) ? rx_ : -INFINITY;
           ry_ = (c >= 1 && c < Tn) ? ry_ : -INFINITY;
         }
-        const float vx = rx_ * kLog2e, vy = ry_ * kLog2e;   // log2 domain
+        const float vx = __builtin_fmaf(rx_, kLog2e, -cx2), vy = __builtin_fmaf(ry_, kLog2e, -cy2);   // log2 domain, shifted (ftr_common.h, Shift)
         nan_acc = max(nan_acc, max(__float_as_uint(vx) & 0x7fffffffu, __float_as_uint(vy) & 0x7fffffffu));
         xs[e] = fmaxf(vx, kNeg);  // -inf -> kNeg (a NaN too: the chain stays finite, the utterance is flagged instead)
         ys[e] = fmaxf(vy, kNeg);
@@ -572,22 +663,51 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     auto clear_imported = [&](int mm) {   // what the COMM wave imported one slot ago: leave it zero for the next launch
       if (has_up && mm >= 0 && mm < klast_up) comm_clear(gran_in, mm, lane);
     };
+    // frame bookkeeping (see "Frames"): while chunk k is handled, frame_k = step[0] + ... + step[k], step_k = step[k],
+    // step_1 / step_2 = the steps already scheduled for chunks k + 1 / k + 2
+    int frame_k = 0, step_k = 0, step_1 = 0, step_2 = 0;
+    bool have_base = false;
+    float mx_prev = -INFINITY;   // the previous chunk's maximum (in that chunk's frame)
+    const bool lane_valid = 64 * w + lane < Sn;
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int k = kc - 1;                 // the chunk the compute wave finished in the previous slot
       if (k >= 0 && k < klast) {
         const float* tp = reinterpret_cast<const float*>(FTR_TP(k));
+        const float plast = tp[((3 * PLANE + lane) << 2) + 3];   // this lane's value after the chunk's last step (for step[k + 3])
+        if (!have_base) {   // chunk 0: the base frame the COMM wave chose (slots ago) counts as chunk 0's step
+          have_base = true;
+          frame_k = step_k = (int)sring[8];
+        }
 #ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
         if (has_down && lane < CH && !(w == 0 && !REVM)) {
 #else
         if (has_down && lane < CH) {   // lane 63's p of the 16 steps of chunk k -> granules of the band below (first: latency critical)
 #endif
           const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
-          const u64 g = ((u64)(unsigned)(k + 1) << 32) | (u64)__float_as_uint(v);
+          const unsigned tag = (unsigned)(k + 1) | ((unsigned)step_k << 16);   // 16-bit signed step above the chunk number
+          const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
           __hip_atomic_store(gran_out + CH * k + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (k == jl / CH && 64 * w + lane < Sn)   // this band's values on the cut (local step jl)
-          pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
+        if (k == jl / CH) {   // this band's values on the cut (local step jl) and the frame they are in
+          if (lane_valid) pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
+          if (lane == 0) __hip_atomic_store(phimid_b + w, frame_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // step[k + 3]: where the largest value will be three chunks from now if it keeps drifting as it did during this
+        // chunk (drift = the change of the maximum plus the step that was taken out of it: absolute positions, so this is
+        // feed-forward, nothing oscillates), centred over that chunk, less the two steps that are already under way
+        const float mx = wave_max_dpp((lane_valid && plast > kNegThresh) ? plast : -INFINITY);
+        int step_3 = 0;
+        if (mx > kNegThresh) {
+          const float drift = (mx_prev > kNegThresh) ? (mx - mx_prev) + (float)step_k : 0.0f;
+          step_3 = min(max((int)__builtin_rintf(mx + 2.5f * drift) - step_1 - step_2, -kStepMax), kStepMax);
+        }
+        mx_prev = mx;
+#ifdef FTR_EXP_NOFRAMES   // study build: no renormalisation
+        step_3 = 0;
+#endif
+        if (lane == 0) sring[(k + 3) & 7] = (float)step_3;
+        frame_k += step_1; step_k = step_1; step_1 = step_2; step_2 = step_3;
       }
       clear_imported(kc - 1 + LOOK);
       if (k >= 0 && k < klast) {
@@ -625,6 +745,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   static_assert(NPF == 4, "the early parks assume four register sets and four input tiles");
   constexpr int kNoChunk = 1 << 20;   // CH * kNoChunk is beyond any slab (and far from overflowing an int offset)
   auto slot_any = [&](int gg, f4 (&x)[4], f4 (&y)[4]) {
+    if (gg == NPF) { cx2 = shift_lds[0]; cy2 = shift_lds[1]; }   // written by the COMM wave in slot 3; the first park is below, in this slot
     const int kp = chained ? (gg < 2 * NPF ? gg - NPF : (gg < 3 * NPF ? -1 : gg - 2 * NPF)) : gg - NPF;
     const int kl = chained && gg >= 2 * NPF ? gg - NPF : gg;
     if (kp >= 0 && kp < klast) {
@@ -639,6 +760,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 #pragma unroll
       for (int u = 0; u < NPF; ++u) {
         const int kc = base + NPF * it + u;
+        if (NPF * it + u == NPF) { cx2 = shift_lds[0]; cy2 = shift_lds[1]; }
         if (kc + kAhead >= 0 && kc + kAhead < klast) park(kc + kAhead, rx[u], ry[u], std::false_type{}, offX, offY);
         if (kc + kAhead + NPF >= 0 && kc + kAhead + NPF < klast) load_general(kc + kAhead + NPF, rx[u], ry[u]);
         FTR_SYNC();
@@ -667,40 +789,55 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
 __device__ __forceinline__ float pmid_load(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void cut_reduce(float* red, float* cache, int cache_n, const float* __restrict__ pa,
-                                           const float* __restrict__ pb, float* __restrict__ ob,
-                                           float* __restrict__ ans_b, int Sn, bool poisoned) {
+__device__ __forceinline__ int phimid_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// p + q of a cut cell = (alpha value + beta value) + (the two bands' frames, integers): formed in double, where the
+// frames (up to ~1e5) cost no precision; everything after the maximum has been subtracted is float again.
+__device__ __forceinline__ void cut_reduce(float* red, double* cache, int cache_n, const float* __restrict__ pa,
+                                           const float* __restrict__ pb, const int* __restrict__ fa,
+                                           const int* __restrict__ fb, float* __restrict__ ob,
+                                           float* __restrict__ ans_b, int Sn, bool poisoned, double shift) {
   // one pass over the (remote) cut values: p + q goes to an LDS cache while the maximum is formed; the sum and the
   // occupancies come from the cache (rows beyond the cache, Sn > cache_n, are re-read)
-  auto val = [&](int r) { return r < cache_n ? cache[r] : pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r); };
-  float m = -INFINITY;
+  auto remote = [&](int r) {
+    const int rb = Sn - 1 - r;
+    return ((double)pmid_load(pa + r) + (double)pmid_load(pb + rb)) + (double)(phimid_load(fa + (r >> 6)) + phimid_load(fb + (rb >> 6)));
+  };
+  auto val = [&](int r) { return r < cache_n ? cache[r] : remote(r); };
+  double* dred = reinterpret_cast<double*>(red);   // 4 doubles (the caller leaves 8 floats)
+  double m = -1.0e300;
   for (int r = threadIdx.x; r < Sn; r += 256) {
-    const float v = pmid_load(pa + r) + pmid_load(pb + Sn - 1 - r);
+    const double v = remote(r);
     if (r < cache_n) cache[r] = v;
-    m = fmaxf(m, v);
+    m = fmax(m, v);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  m = wave_max_f64(m);
+  if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  m = fmax(fmax(dred[0], dred[1]), fmax(dred[2], dred[3]));
   __syncthreads();
   float sum = 0.0f;
-  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f(val(r) - m);
+  for (int r = threadIdx.x; r < Sn; r += 256) sum += exp2f((float)(val(r) - m));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
   __syncthreads();
   sum = (red[0] + red[1]) + (red[2] + red[3]);
-  const float total = m + log2f(sum);
-  const bool dead = !(total > kNegThresh);      // no path: ans = -inf, no flow
+  const double total = m + (double)log2f(sum);
+  const bool dead = !(total > (double)kNegThresh);      // no path: ans = -inf, no flow
   // a NaN among the inputs of this utterance, or a band that gave up waiting: ans = NaN (loud), no flow
-  if (threadIdx.x == 0) *ans_b = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : total * kLn2);
-  // normalised with the very sum they add up to (not with exp2(-total)): the injected occupancies sum to 1 to
-  // rounding, whatever the magnitude of p + q (thousands on long utterances)
+  // `shift`: what the per-utterance operand shift (ftr_common.h, Shift) took out of every complete path, log2 units
+  if (threadIdx.x == 0) *ans_b = poisoned ? __builtin_nanf("") : (dead ? -INFINITY : (float)((total + shift) * 0.6931471805599453));
+  // normalised with the very sum they add up to (not with exp2(-total)): the injected occupancies sum to 1 to rounding
   const float inv = 1.0f / sum;
   for (int r = threadIdx.x; r < Sn; r += 256)
-    ob[r] = (dead || poisoned) ? 0.0f : exp2f(val(r) - m) * inv;
+    ob[r] = (dead || poisoned) ? 0.0f : exp2f((float)(val(r) - m)) * inv;
 }
 
 struct Ctrl {           // int offsets into the ctrl block of the workspace
@@ -713,8 +850,8 @@ __device__ __forceinline__ Ctrl ctrl_of(int* ctrl, int B) {
 template <bool MOD>
 __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
     const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
-    float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, float* __restrict__ occ,
-    int* __restrict__ ctrl, float* __restrict__ ans, int B, int NB, int Tg, int S, int T) {
+    float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, float* __restrict__ occ, float* __restrict__ cxy,
+    int* __restrict__ phimid, int* __restrict__ ctrl, float* __restrict__ ans, int B, int NB, int Tg, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // band-major block ids: producers (lower band index) have lower ids.  Forward progress of a band that waits for the
   // band above relies on the dispatcher starting workgroups in id order (true on this hardware; an oversubscribed grid
@@ -742,8 +879,9 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
   float* pmid_b = pmid + ((size_t)dir * B + b) * (S + 1);
   const Ctrl c = ctrl_of(ctrl, B);
-  if (dir == 0) bidir_fwd_body<MOD, false>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, b, w, Tg, S, T, cut.jm);
-  else bidir_fwd_body<MOD, true>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, b, w, Tg, S, T, cut.D - cut.jm);
+  int* phimid_b = phimid + ((size_t)dir * B + b) * NB;   // frame of each band's cut values (see "Frames" in the body)
+  if (dir == 0) bidir_fwd_body<MOD, false>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, cxy + 2 * b, phimid_b, b, w, Tg, S, T, cut.jm);
+  else bidir_fwd_body<MOD, true>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, cxy + 2 * b, phimid_b, b, w, Tg, S, T, cut.D - cut.jm);
 
   // ---- the last of the 2 * NWact bands of this utterance to get here runs the cut reduction
   __builtin_amdgcn_s_waitcnt(kVmcnt0);           // this wave's cut values / flags have left
@@ -765,8 +903,11 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
     __hip_atomic_store(c.done + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(c.uflags + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  cut_reduce(reinterpret_cast<float*>(smem) + 4, reinterpret_cast<float*>(smem) + 8, 8192, pmid + (size_t)b * (S + 1),
-             pmid + ((size_t)B + b) * (S + 1), occ + (size_t)b * (S + 1), ans + b, Sn, (uf | stt) != 0);
+  Shift sh;   // written by the first alpha band of this utterance (write-through stores, long before its done[] increment)
+  sh.cx2 = pmid_load(cxy + 2 * b); sh.cy2 = pmid_load(cxy + 2 * b + 1);
+  cut_reduce(reinterpret_cast<float*>(smem) + 4, reinterpret_cast<double*>(smem) + 8, 4096, pmid + (size_t)b * (S + 1),
+             pmid + ((size_t)B + b) * (S + 1), phimid + (size_t)b * NB, phimid + ((size_t)B + b) * NB, occ + (size_t)b * (S + 1),
+             ans + b, Sn, (uf | stt) != 0, shift_total<MOD>(sh, Sn, Tn));
 }
 
 // ---------------------------------------------------------------------------------------------------- flow
@@ -1320,7 +1461,7 @@ inline int allow_big_lds(K kernel, const char* what) {
 
 struct BidirLayout {
   size_t lat;       // floats per ratio lattice (padded)
-  size_t pmid_off, occ_off, seed_off, ctrl_off, gran_off, total;   // float offsets
+  size_t pmid_off, occ_off, seed_off, cxy_off, phi_off, ctrl_off, gran_off, total;   // float offsets
   size_t ctrl_floats, gran_floats;                                   // ctrl block; ONE granule region (forward or flow)
   int NB, Tg;
 };
@@ -1331,7 +1472,10 @@ inline BidirLayout bidir_layout(int B, int S, int T) {
   l.pmid_off = kLatPad + 2 * l.lat;
   l.occ_off = l.pmid_off + 2 * (size_t)B * (S + 1);
   l.seed_off = l.occ_off + (size_t)B * (S + 1);
-  l.ctrl_off = (l.seed_off + (size_t)B + 3) & ~(size_t)3;
+  l.cxy_off = l.seed_off + (size_t)B;                                // shift constants, two per utterance
+  l.NB = (S + 1 + 63) / 64;
+  l.phi_off = l.cxy_off + 2 * (size_t)B;                             // frame of every band's cut values, int per (direction, utterance, band)
+  l.ctrl_off = (l.phi_off + 2 * (size_t)B * l.NB + 3) & ~(size_t)3;
   l.ctrl_floats = ((size_t)4 + 2 * (size_t)B + 3) & ~(size_t)3;     // status + pad, done[B], uflags[B]
   l.gran_off = l.ctrl_off + l.ctrl_floats;
   l.NB = (S + 1 + 63) / 64;
@@ -1421,6 +1565,7 @@ int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, floa
   const BidirLayout l = bidir_layout(B, S, T);
   int rc = check_ws("mutual_information_fwd", ws, ws_floats, l);
   if (rc != FTR_OK) return rc;
+  if (l.Tg / CH >= (int)kTagChunkMask) { set_error("mutual_information_fwd: T = %d is beyond the %u chunks a granule tag can number", T, kTagChunkMask); return FTR_ERR_UNSUPPORTED; }
   if (!(flags & FTR_MI_WS_CLEAN)) { rc = clear_handoff("mutual_information_fwd", ws, l, st); if (rc != FTR_OK) return rc; }
   u64* gran = reinterpret_cast<u64*>(ws + l.gran_off);
   int* ctrl = reinterpret_cast<int*>(ws + l.ctrl_off);
@@ -1433,8 +1578,8 @@ int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, floa
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ctrl, ans, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ctrl, ans, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ws + l.cxy_off, reinterpret_cast<int*>(ws + l.phi_off), ctrl, ans, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ws + l.cxy_off, reinterpret_cast<int*>(ws + l.phi_off), ctrl, ans, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_fwd");
 }
 
