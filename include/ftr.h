@@ -59,10 +59,23 @@ size_t ftr_mutual_information_workspace_floats(int B, int S, int T);
 #define FTR_MI_WS_CLEAN 1 /* the hand-off region of `p` is known to be all zero: it was zeroed once by
                              ftr_mutual_information_workspace_init() and since then only touched by launches of this
                              library that completed with status 0 (they leave it zero again).  Saves the memset node
-                             in front of the forward launch.  The promise holds for the (B,S,T) the buffer was
-                             initialised for; graph capture / replay is fine (nothing depends on a launch counter). */
+                             in front of the forward launch.  Graph capture / replay is fine (nothing depends on a
+                             launch counter).
+                             ONE BUFFER FOR MANY SHAPES.  The hand-off region of a launch is the LAST
+                             ftr_mutual_information_handoff_floats(B,S,T) floats of the buffer it is given (p + p_floats
+                             is what anchors it), everything else grows from the front.  A caller whose (B,S,T) change
+                             from step to step (padded batches) keeps one buffer of
+                                 max over shapes of (workspace_floats - handoff_floats)  +  max over shapes of handoff_floats
+                             floats, zeroes its last max-handoff floats once (workspace_init with p_floats = the whole
+                             buffer and the shape with the largest hand-off part, or a memset), always passes the whole
+                             buffer, and may then pass FTR_MI_WS_CLEAN for every one of those shapes: no per-step
+                             allocation, no per-step memset (tf_fast_rnnt/mutual_information.py does exactly this). */
 
-/* Zeroes the hand-off region of a workspace (asynchronous on `stream`).  Once per buffer and problem size. */
+/* floats of the hand-off region (control block + granules) within ftr_mutual_information_workspace_floats(B,S,T) */
+size_t ftr_mutual_information_handoff_floats(int B, int S, int T);
+
+/* Zeroes the hand-off region of a workspace (asynchronous on `stream`): the last handoff_floats(B,S,T) floats of
+ * p[0, p_floats).  Once per buffer (see FTR_MI_WS_CLEAN). */
 int ftr_mutual_information_workspace_init(float* p, size_t p_floats, int B, int S, int T, void* stream);
 
 /* Reads back the sticky status word of a workspace (SYNCHRONISES `stream`): 0 = fine; bit 0 = some band gave up
@@ -354,7 +367,11 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
  * PRECONDITION on `ranges` (what get_rnnt_prune_ranges produces): for every utterance ranges[b,t,0] is non-decreasing in
  * t over the frames of the boundary rectangle.  ftr_mutual_information_band_f32 checks it on the device and answers a
  * violation with ans[b] = NaN and zero occupancies; callers with arbitrary ranges use ftr_pruned_logprobs_* + the lattice
- * recursion (the Python layer routes only ranges that come straight from get_rnnt_prune_ranges here).
+ * recursion.  The band entry points also read ranges[b,t,0] only (row k of a frame is lattice row ranges[b,t,0] + k).
+ * ftr_band_ranges_check_i32 tells whether a ranges tensor is such a band: flags[0] (device int, written) = 0 when it is,
+ * bit 0 = not monotone, bit 1 = ranges[b,t,k] != ranges[b,t,0] + k somewhere, both inside the boundary rectangles only
+ * (the Python layer runs it once per ranges tensor that does not come straight from get_rnnt_prune_ranges and routes
+ * by the answer).
  * ftr_mutual_information_band_supported(T, S, r): 1 = the LDS-resident kernel (r <= 15 and 12 (S + T + 21) LANES +
  * 4 (T + 34) bytes <= 150 KB with LANES = 8 for r <= 7, else 16); 2 = the streaming kernel for longer utterances, which
  * keeps its wavefront-ordered arrays in a caller-provided workspace of ftr_mutual_information_band_workspace_floats()
@@ -362,6 +379,7 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
  * 0 = outside both (r > 15).  ftr_mutual_information_band_f32 is the _ws form without a workspace (kind 1 only).
  */
 int ftr_mutual_information_band_supported(int T, int S, int r);
+int ftr_band_ranges_check_i32(const int32_t* ranges, const int32_t* boundary, int32_t* flags, int B, int T, int r, void* stream);
 size_t ftr_mutual_information_band_workspace_floats(int B, int T, int S, int r);
 int ftr_mutual_information_band_ws_f32(const float* px_band, const float* py_band, const int32_t* ranges,
                                        const int32_t* boundary, float* workspace, size_t workspace_floats, float* ans,

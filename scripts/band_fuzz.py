@@ -1,5 +1,5 @@
 """Randomised comparison of the two routes of rnnt_loss_pruned: the band-native recursion (ranges straight from
-get_rnnt_prune_ranges) against the full-lattice route (an unmarked copy of the same ranges).
+get_rnnt_prune_ranges, or a clone of them) against the full-lattice route (FTR_PRUNED_ROUTE=lattice).
 python scripts/band_fuzz.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,14 +27,17 @@ def main(n=100, seed=0):
         am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
         base = torch.tanh(am_p + lm_p).detach()
         outs = []
-        for rg in (ranges, ranges.clone()):
+        for route in ("band", "lattice"):
+            os.environ["FTR_PRUNED_ROUTE"] = route
+            rg = ranges.clone() if it % 2 else ranges       # a clone carries no mark: it is checked on the device and takes the same route
             logits = base.clone().requires_grad_(True)
             loss = ft.rnnt_loss_pruned(logits, sym, rg, blank, bd, rt, 0.1, "none")
             fin = torch.isfinite(loss)
             if fin.any(): loss[fin].sum().backward()
             outs.append((loss.detach().cpu().numpy(), np.zeros(base.shape, np.float32) if logits.grad is None else logits.grad.cpu().numpy()))
+        os.environ["FTR_PRUNED_ROUTE"] = "band"
         from tf_fast_rnnt.rnnt_loss import _band_path_ok
-        band += int(_band_path_ok(ranges, T, S, ranges.shape[2]))
+        band += int(_band_path_ok(ranges, bd, T, S, ranges.shape[2]))
         f0, f1 = np.isfinite(outs[0][0]), np.isfinite(outs[1][0])
         assert np.array_equal(f0, f1), (it, B, T, S, C, r, rt, outs[0][0], outs[1][0])
         if f0.any():

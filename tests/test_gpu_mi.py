@@ -360,6 +360,40 @@ def test_workspace_stays_clean_across_launches(ft, dev, modified):
             assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
 
 
+def test_one_workspace_serves_a_ragged_loop(ft, dev):
+    """A training loop pads every batch to its own maximum: 20 steps with 20 different (B, S, T).  The cached workspace is
+    sized by capacity (hand-off region anchored at the end of the buffer, include/ftr.h FTR_MI_WS_CLEAN), so the loop
+    allocates / zeroes when the capacity has to GROW only -- once when the largest shape comes first -- and every step's
+    results are bit-identical to the same launch on a fresh, exactly-sized, freshly initialised workspace."""
+    from tf_fast_rnnt import mutual_information as M
+    from tf_fast_rnnt.mutual_information import mi_forward_backward
+    rng = np.random.default_rng(11)
+    shapes = [(6, 150, 400)] + [(int(rng.integers(1, 7)), int(rng.integers(1, 151)), int(rng.integers(2, 401))) for _ in range(19)]
+    L = ft._lib.lib()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    M.clear_workspace_cache()
+    inits0 = M._Workspace.inits
+    for i, (B, S, T) in enumerate(shapes):
+        px, py, bd = random_lattice(1000 + i, B, S, T, modified=bool(i % 2), ragged=True, begin_offsets=bool(i % 3 == 0))
+        ans, gx, gy = mi_forward_backward(t(px), t(py), t(bd), True)
+        # the same launches on a private workspace of exactly this shape's size
+        nws = L.ftr_mutual_information_workspace_floats(B, S, T)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        a2, gx2, gy2, _ = _raw_ws_calls(ft, dev, t(px), t(py), t(bd), ws, 0, modified=i % 2)
+        torch.cuda.synchronize()
+        assert np.array_equal(ans.cpu().numpy(), a2.cpu().numpy(), equal_nan=True), (i, B, S, T)
+        assert torch.equal(gx, gx2) and torch.equal(gy, gy2), (i, B, S, T)
+    assert M._Workspace.inits - inits0 == 1, M._Workspace.inits - inits0
+    assert M.check_workspace_status() == 0
+    # growth: a larger shape reallocates once, after which the earlier shapes still fit
+    px, py, bd = random_lattice(7, 8, 200, 500, ragged=True)
+    mi_forward_backward(t(px), t(py), t(bd), True)
+    px, py, bd = random_lattice(8, 2, 30, 50, ragged=True)
+    mi_forward_backward(t(px), t(py), t(bd), True)
+    assert M._Workspace.inits - inits0 == 2
+    M.clear_workspace_cache()
+
+
 def test_undersized_workspace_is_refused(ft, dev):
     """A buffer of the reference's p shape [B,S+1,T+1] is too small for the two-lattice workspace: the _ws entry points
     return FTR_ERR_INVALID_ARG instead of writing past its end."""

@@ -504,9 +504,9 @@ def test_fused_smoothed_loss_matches_composed_path(ft, dev, reduction, rnnt_type
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
 @pytest.mark.parametrize("cfg", [(3, 40, 12, 20, 4), (2, 90, 33, 12, 5), (4, 64, 20, 16, 2), (2, 130, 50, 24, 8), (2, 70, 40, 8, 16), (2, 70, 40, 8, 15), (2, 60, 30, 8, 7),
                                  (3, 33, 5, 7, 3), (2, 200, 50, 50, 5), (1, 300, 10, 16, 11), (2, 25, 20, 8, 6)])
-def test_band_native_pruned_loss_matches_lattice_path(ft, dev, oracle, rnnt_type, cfg):
-    """rnnt_loss_pruned on the band itself (ftr_mutual_information_band_f32: ranges carrying get_rnnt_prune_ranges' mark)
-    against the same loss through full-size lattices (an unmarked copy of the same ranges): loss and d/d logits, ragged
+def test_band_native_pruned_loss_matches_lattice_path(ft, dev, oracle, rnnt_type, cfg, monkeypatch):
+    """rnnt_loss_pruned on the band itself (ftr_mutual_information_band_f32) against the same loss through full-size
+    lattices (FTR_PRUNED_ROUTE=lattice): loss and d/d logits, ragged
     boundaries, delay penalty, non-trivial upstream gradient.  Two float32 evaluations of the same quantity: 1e-4 on the
     loss, 2e-4 normwise on the gradient (observed ~1e-6 / ~1e-5); and both against the float64 oracle."""
     B, T, S, C, r = cfg
@@ -515,14 +515,14 @@ def test_band_native_pruned_loss_matches_lattice_path(ft, dev, oracle, rnnt_type
     am, lm, sym, bd = (_t(d[k], dev) for k in ("am", "lm", "symbols", "boundary"))
     _, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, rnnt_type, reduction="sum", calc_gradients=True)
     ranges = ft.get_rnnt_prune_ranges(gx, gy, bd, r)
-    assert getattr(ranges, "_ftr_monotone", False)
     am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
     base = torch.tanh(am_p + lm_p).detach()
     wgt = torch.rand((B,), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev) + 0.5
     outs = []
-    for rg in (ranges, ranges.clone()):
+    for route in ("band", "lattice"):
+        monkeypatch.setenv("FTR_PRUNED_ROUTE", route)
         logits = base.clone().requires_grad_(True)
-        loss = ft.rnnt_loss_pruned(logits, sym, rg, blank, bd, rnnt_type, 0.1, "none")
+        loss = ft.rnnt_loss_pruned(logits, sym, ranges, blank, bd, rnnt_type, 0.1, "none")
         (loss * wgt).sum().backward()
         outs.append((loss.detach().cpu().numpy(), logits.grad.cpu().numpy()))
     fin = np.isfinite(outs[1][0])
@@ -534,6 +534,59 @@ def test_band_native_pruned_loss_matches_lattice_path(ft, dev, oracle, rnnt_type
                                                    delay_penalty=0.1, reduction="none", dtype=np.float64)
         np.testing.assert_allclose(outs[0][0][fin], o_loss[fin], rtol=1e-4)
         assert max_rel(outs[0][1][fin], (o_g * wgt.cpu().numpy().reshape(-1, 1, 1, 1))[fin]) <= 2e-4
+
+
+def test_pruned_loss_routes_by_the_data_not_by_a_mark(ft, dev, monkeypatch):
+    """A clone / a slice / a reloaded copy of get_rnnt_prune_ranges' output carries no mark and must still take the
+    band-native route (one device-side check, remembered on the tensor); a ranges tensor that is NOT a band (non-monotone,
+    or rows that are not consecutive) must take the lattice route and give the lattice route's answer; an in-place edit
+    invalidates what was remembered."""
+    import io
+    from tf_fast_rnnt import _lib
+    from tf_fast_rnnt.rnnt_loss import _is_band
+    B, T, S, C, r = 3, 90, 33, 12, 5
+    d = synthetic(321, B, T, S, C, ragged=True)
+    blank = d["termination_symbol"]
+    am, lm, sym, bd = (_t(d[k], dev) for k in ("am", "lm", "symbols", "boundary"))
+    _, (gx, gy) = ft.rnnt_loss_simple(lm, am, sym, blank, bd, reduction="sum", calc_gradients=True)
+    ranges = ft.get_rnnt_prune_ranges(gx, gy, bd, r)
+    am_p, lm_p = ft.do_rnnt_pruning(am, lm, ranges)
+    logits = torch.tanh(am_p + lm_p).detach()
+    calls = []
+    real_call = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real_call(name, *a))[1])
+    buf = io.BytesIO(); torch.save(ranges.cpu(), buf); buf.seek(0)
+    want = ft.rnnt_loss_pruned(logits, sym, ranges, blank, bd, reduction="none").cpu().numpy()
+    assert "ftr_mutual_information_band_ws_f32" in calls and "ftr_band_ranges_check_i32" not in calls    # marked: no check
+    for other in (ranges.clone(), ranges[:, :, :].contiguous(), torch.load(buf, weights_only=True).to(dev), ranges.to(torch.int64)):
+        calls.clear()
+        got = ft.rnnt_loss_pruned(logits, sym, other, blank, bd, reduction="none").cpu().numpy()
+        assert "ftr_mutual_information_band_ws_f32" in calls and "ftr_pruned_logprobs_fwd_f32" not in calls
+        assert np.array_equal(got, want)                      # the same kernels on the same data
+    c = ranges.clone()
+    calls.clear(); ft.rnnt_loss_pruned(logits, sym, c, blank, bd, reduction="none")
+    assert calls.count("ftr_band_ranges_check_i32") == 1
+    calls.clear(); ft.rnnt_loss_pruned(logits, sym, c, blank, bd, reduction="none")
+    assert "ftr_band_ranges_check_i32" not in calls           # the verdict is remembered
+    # not a band: one frame steps backwards (utterance 1), or a row is not consecutive (utterance 2)
+    for edit in ("backwards", "gap"):
+        bad = ranges.clone()
+        assert _is_band(bad, bd)
+        t0 = int(bd[1, 3].item()) // 2
+        if edit == "backwards":
+            bad[1, t0] = torch.clamp(bad[1, t0 - 1] - 1, min=0)      # in-place: the remembered verdict must not survive
+        else:
+            bad[2, 3, r - 1] = bad[2, 3, r - 1] - 1
+        if edit == "backwards" and int(bad[1, t0, 0]) >= int(bad[1, t0 - 1, 0]):
+            continue                                                 # already at row 0: nothing to break
+        assert not _is_band(bad, bd)
+        calls.clear()
+        got = ft.rnnt_loss_pruned(logits, sym, bad, blank, bd, reduction="none").cpu().numpy()
+        assert "ftr_pruned_logprobs_fwd_f32" in calls and "ftr_mutual_information_band_ws_f32" not in calls
+        monkeypatch.setenv("FTR_PRUNED_ROUTE", "lattice")
+        ref = ft.rnnt_loss_pruned(logits, sym, bad.clone(), blank, bd, reduction="none").cpu().numpy()
+        monkeypatch.delenv("FTR_PRUNED_ROUTE")
+        assert np.array_equal(got, ref, equal_nan=True)
 
 
 def test_out_of_range_caller_data_does_not_fault(ft, dev):

@@ -50,7 +50,7 @@ using namespace ftr;
 
 extern "C" {
 
-int ftr_abi_version(void) { return 120; }
+int ftr_abi_version(void) { return 130; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
@@ -66,6 +66,11 @@ size_t ftr_mutual_information_workspace_floats(int B, int S, int T) {
   // the bidirectional wavefront kernels: two ratio lattices, the cut vectors and the hand-off region
   // (mi_wave_bidir.hip); the plain family's p lattice fits in the same buffer
   return mi_bidir_workspace_floats(B, S, T);
+}
+
+size_t ftr_mutual_information_handoff_floats(int B, int S, int T) {
+  if (B < 0 || S < 0 || T < 0) return 0;
+  return mi_bidir_handoff_floats(B, S, T);
 }
 
 namespace {
@@ -594,6 +599,15 @@ int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const i
   rc = lse_rows(logits, lse, (size_t)B * T * r, C, st);
   if (rc != FTR_OK) return rc;
   return band_gather(logits, symbols, ranges, boundary, lse, termination_symbol, delay_penalty, px_band, py_band, B, T, S, C, r, modified, st);
+}
+
+int ftr_band_ranges_check_i32(const int32_t* ranges, const int32_t* boundary, int32_t* flags, int B, int T, int r, void* stream) {
+  clear_error();
+  FTR_REQUIRE(B >= 0 && T >= 0 && r >= 1, "band_ranges_check: bad sizes");
+  FTR_REQUIRE(flags && (ranges || B == 0 || T == 0), "band_ranges_check: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return band_ranges_check(ranges, boundary, flags, B, T, r, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_mutual_information_band_f32(const float* px_band, const float* py_band, const int32_t* ranges,

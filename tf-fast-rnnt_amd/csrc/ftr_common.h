@@ -123,6 +123,7 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int
 int mi_bidir_ws_init(float* ws, size_t ws_floats, int B, int S, int T, hipStream_t st);
 int mi_bidir_status(const float* ws, size_t ws_floats, int B, int S, int T, int* status_host, long long* dirty_host, hipStream_t st);
 size_t mi_bidir_workspace_floats(int B, int S, int T);
+size_t mi_bidir_handoff_floats(int B, int S, int T);
 int cummin_i32(const int32_t* in, int32_t* out, int rows, int cols, hipStream_t st);
 int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boundary, int32_t* ranges, int32_t* s_begin, int B, int S, int T, int T1, int r, hipStream_t st);
 int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* am_p, float* lm_p, int B, int T, int S1, int C, int r, hipStream_t st);
@@ -145,6 +146,7 @@ int simple_fused_bwd_am(const float* gpx, const float* gpy, Scale scale, const f
 int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);
 int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st);
 int mi_band_supported(int T, int S, int r);
+int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st);
 int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 size_t mi_band_workspace_floats(int B, int T, int S, int r);
 int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ws, size_t ws_floats, float* ans, float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st);

@@ -84,6 +84,31 @@ __global__ void band_gather_kernel(const float* __restrict__ logits, const int32
   pyb[row] = vy;
 }
 
+// ---------------------------------------------------------------------------------------- are these ranges a band?
+// What the band kernels assume of `ranges` inside each utterance's boundary rectangle (frames [t_begin, t_end)):
+// bit 0 of flags[0] is set when some ranges[b,t,0] < ranges[b,t-1,0] (not monotone), bit 1 when some
+// ranges[b,t,k] != ranges[b,t,0] + k (not contiguous).  One thread per frame; flags[0] must be zero beforehand.
+__global__ void band_ranges_check_kernel(const int32_t* __restrict__ ranges, const int32_t* __restrict__ boundary,
+                                         int* __restrict__ flags, int B, int T, int r) {
+  const size_t bt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int bad = 0;
+  if (bt < (size_t)B * T) {
+    const int b = (int)(bt / T), t = (int)(bt - (size_t)b * T);
+    const int tb = boundary ? max(boundary[4 * b + 1], 0) : 0, te = boundary ? min(boundary[4 * b + 3], T) : T;
+    if (t >= tb && t < te) {
+      const int32_t* row = ranges + bt * r;
+      const int s0 = row[0];
+      if (t > tb && s0 < row[-r]) bad |= 1;
+      for (int k = 1; k < r; ++k) if (row[k] != s0 + k) bad |= 2;
+    }
+  }
+  if (__any(bad != 0)) {
+    int all = 0;
+    for (int bit = 1; bit <= 2; bit <<= 1) if (__any((bad & bit) != 0)) all |= bit;
+    if ((threadIdx.x & 63) == 0) atomicOr(flags, all);
+  }
+}
+
 // ---------------------------------------------------------------------------------------- the band recursion
 // Wavefront-ordered arrays, [row][lane], LANES lanes per row:
 //   rows 0 .. 2U-1         only ever fetched ahead, never used
@@ -764,6 +789,14 @@ size_t mi_band_workspace_floats(int B, int T, int S, int r) {
   if (mi_band_supported(T, S, r) != 2) return 0;
   const size_t per = band_stream_lanes(T, r) == 8 ? band_stream_floats_per_utt<8>(T, S) : band_stream_floats_per_utt<16>(T, S);
   return per * (size_t)B;
+}
+
+int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st) {
+  if (hipMemsetAsync(flags, 0, sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); set_error("band_ranges_check: memset failed"); return FTR_ERR_LAUNCH; }
+  const size_t n = (size_t)B * T;
+  if (n == 0) return FTR_OK;
+  hipLaunchKernelGGL(band_ranges_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ranges, boundary, flags, B, T, r);
+  return check_launch("band_ranges_check");
 }
 
 int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary,

@@ -28,13 +28,13 @@
 // forward beta and flow alpha use REV.
 //
 // Workspace ("p" in the C ABI), floats:  [ G_alpha lattice | G_beta lattice | pmid 2*B*(S+1) | occ B*(S+1) | seed B | shift 2*B | cut frames 2*B*NB | pad |
-//                                          ctrl: status word, done[B], uflags[B] | pad |
-//                                          granules of the forward launch 2*B*NB*Tg*8 bytes | granules of the flow launch ].
+//                                          ctrl: pad, done[B], uflags[B] | pad |
+//                                          granules of the forward launch 2*B*NB*Tg*8 bytes | granules of the flow launch | status (4) ].
 // "ctrl + granules" is the HAND-OFF region: it must be all zero when a launch starts.  The launches leave it all zero
 // again (every consumer clears the granules it has imported, the last workgroup of an utterance clears its counters),
 // so a caller that initialised the workspace once (ftr_mutual_information_workspace_init) passes FTR_MI_WS_CLEAN and no
 // memset node is needed; without the flag the launchers zero the region themselves.
-//   status   sticky: bit 0 = a band gave up waiting for its producer (the results of that launch are poisoned)
+//   status   (the last block, at the same address for every shape launched on one buffer) sticky: bit 0 = a band gave up waiting for its producer (the results of that launch are poisoned)
 //   done[b]  bands of utterance b that have delivered their cut values (the last one runs the cut reduction)
 //   uflags[b] bit 1 = a NaN was read from px / py inside the boundary rectangle of utterance b  ->  ans[b] = NaN
 #include "ftr_common.h"
@@ -843,15 +843,16 @@ __device__ __forceinline__ void cut_reduce(float* red, double* cache, int cache_
 struct Ctrl {           // int offsets into the ctrl block of the workspace
   int* status; int* done; int* uflags;
 };
-__device__ __forceinline__ Ctrl ctrl_of(int* ctrl, int B) {
-  Ctrl c; c.status = ctrl; c.done = ctrl + 4; c.uflags = ctrl + 4 + B; return c;
+// the status word is the hand-off region's LAST block (4 ints): the same address for every shape launched on one buffer
+__device__ __forceinline__ Ctrl ctrl_of(int* ctrl, int B, int soff) {
+  Ctrl c; c.status = ctrl + soff; c.done = ctrl + 4; c.uflags = ctrl + 4 + B; return c;
 }
 
 template <bool MOD>
 __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
     const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ boundary,
     float* __restrict__ ws, u64* __restrict__ gran, float* __restrict__ pmid, float* __restrict__ occ, float* __restrict__ cxy,
-    int* __restrict__ phimid, int* __restrict__ ctrl, float* __restrict__ ans, int B, int NB, int Tg, int S, int T) {
+    int* __restrict__ phimid, int* __restrict__ ctrl, int soff, float* __restrict__ ans, int B, int NB, int Tg, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // band-major block ids: producers (lower band index) have lower ids.  Forward progress of a band that waits for the
   // band above relies on the dispatcher starting workgroups in id order (true on this hardware; an oversubscribed grid
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(256) void mi_bidir_fwd_kernel(
   float* wsb = ws + kLatPad + (size_t)dir * lattice_floats(B, S, T) + (size_t)b * (S + 1) * (T + 1);
   u64* gran_b = gran + ((size_t)dir * B + b) * NB * Tg;
   float* pmid_b = pmid + ((size_t)dir * B + b) * (S + 1);
-  const Ctrl c = ctrl_of(ctrl, B);
+  const Ctrl c = ctrl_of(ctrl, B, soff);
   int* phimid_b = phimid + ((size_t)dir * B + b) * NB;   // frame of each band's cut values (see "Frames" in the body)
   if (dir == 0) bidir_fwd_body<MOD, false>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, cxy + 2 * b, phimid_b, b, w, Tg, S, T, cut.jm);
   else bidir_fwd_body<MOD, true>(smem, pxb, pyb, bd, wsb, gran_b, pmid_b, c.status, c.uflags + b, cxy + 2 * b, phimid_b, b, w, Tg, S, T, cut.D - cut.jm);
@@ -1365,7 +1366,7 @@ template <bool MOD>
 __global__ __launch_bounds__(kFlowThreads) void mi_bidir_flow_kernel(
     const int32_t* __restrict__ boundary, const float* __restrict__ ws, u64* __restrict__ gran,
     const float* __restrict__ occ, float* __restrict__ px_grad, float* __restrict__ py_grad,
-    const float* __restrict__ seed, float* __restrict__ check, int* __restrict__ ctrl, int B, int NB, int Tg, int S, int T) {
+    const float* __restrict__ seed, float* __restrict__ check, int* __restrict__ status, int B, int NB, int Tg, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NOFF = MOD ? 1 : 0;
   const int b2 = blockIdx.x % (2 * B);
@@ -1426,8 +1427,8 @@ __global__ __launch_bounds__(kFlowThreads) void mi_bidir_flow_kernel(
   // dir 1 holds the beta ratios: its flow runs in FWD addressing from the cut (walk step jm) to the end cell.
   // `seed` (the incoming ans_grad, never written by this launch) and `check` (p_grad at the origin, written by the band
   // that reaches it) are different buffers: no workgroup reads what another one writes
-  if (dir == 0) bidir_flow_body<MOD, true>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, check, ctrl, b, w, Tg, S, T, cut.D - cut.jm);
-  else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, nullptr, ctrl, b, w, Tg, S, T, cut.jm);
+  if (dir == 0) bidir_flow_body<MOD, true>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, check, status, b, w, Tg, S, T, cut.D - cut.jm);
+  else bidir_flow_body<MOD, false>(smem, bd, wsb, gran_b, occ_b, pxg, pyg, seed, nullptr, status, b, w, Tg, S, T, cut.jm);
 #if defined(FTR_TRACE) && FTR_TRACE == 2
   __builtin_amdgcn_s_waitcnt(kVmcnt0);
   if (lane == 0) { const u64 t = trace_now(); atomicMax(&g_trace[1], t); if (wid == 0 && b == 0 && dir == FTR_TRACE_DIR && w == FTR_STAMP_BAND) g_trace[3] = t; }
@@ -1485,6 +1486,20 @@ inline BidirLayout bidir_layout(int B, int S, int T) {
   return l;
 }
 
+// The hand-off region (ctrl + granules) sits at the END of the buffer the caller passes, whatever the buffer's size:
+// a caller that keeps ONE buffer for many shapes (capacity = the largest data part + the largest hand-off part it has
+// seen) zeroes the tail once, and every shape's hand-off region lies inside that tail and is left clean by every launch,
+// while the data parts grow from the front and never reach it.  With a buffer of exactly `total` floats this is the
+// layout above.  ws_floats == (size_t)-1: size unknown (the entry points without a size), taken as exact.
+inline BidirLayout anchored(BidirLayout l, size_t ws_floats) {
+  if (ws_floats == (size_t)-1 || ws_floats < l.total) return l;
+  const size_t delta = (ws_floats - l.total) & ~(size_t)3;
+  l.ctrl_off += delta; l.gran_off += delta; l.total += delta;
+  return l;
+}
+inline size_t handoff_floats(const BidirLayout& l) { return l.total - l.ctrl_off; }
+inline size_t status_off(const BidirLayout& l) { return l.total - 4; }   // the last block of the (anchored) hand-off region
+
 // ---------------------------------------------------------------------------------------------
 // Hardware self-test: the wavefront kernels rely on (1) wave_shr:1 DPP shifting across all 64 lanes
 // with lane 0 keeping `old`, (2) 16-byte global loads/stores at 4-byte alignment.  result[0] = 1 if
@@ -1509,6 +1524,7 @@ __global__ void selftest_kernel(const float* __restrict__ in, float* __restrict_
 
 // floats of workspace the bidirectional kernels need in total
 size_t mi_bidir_workspace_floats(int B, int S, int T) { return bidir_layout(B, S, T).total; }
+size_t mi_bidir_handoff_floats(int B, int S, int T) { return handoff_floats(bidir_layout(B, S, T)); }
 
 namespace {
 int check_ws(const char* what, const float* ws, size_t ws_floats, const BidirLayout& l) {
@@ -1530,7 +1546,7 @@ int clear_handoff(const char* what, float* ws, const BidirLayout& l, hipStream_t
 }  // namespace
 
 int mi_bidir_ws_init(float* ws, size_t ws_floats, int B, int S, int T, hipStream_t st) {
-  const BidirLayout l = bidir_layout(B, S, T);
+  const BidirLayout l = anchored(bidir_layout(B, S, T), ws_floats);
   int rc = check_ws("mutual_information_workspace_init", ws, ws_floats, l);
   if (rc != FTR_OK) return rc;
   return clear_handoff("mutual_information_workspace_init", ws, l, st);
@@ -1538,22 +1554,22 @@ int mi_bidir_ws_init(float* ws, size_t ws_floats, int B, int S, int T, hipStream
 
 int mi_bidir_status(const float* ws, size_t ws_floats, int B, int S, int T, int* status_host, long long* dirty_host,
                     hipStream_t st) {
-  const BidirLayout l = bidir_layout(B, S, T);
+  const BidirLayout l = anchored(bidir_layout(B, S, T), ws_floats);
   int rc = check_ws("mutual_information_status", ws, ws_floats, l);
   if (rc != FTR_OK) return rc;
-  if (hipMemcpyAsync(status_host, ws + l.ctrl_off, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  if (hipMemcpyAsync(status_host, ws + status_off(l), sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {
     (void)hipGetLastError(); set_error("mutual_information_status: copy failed"); return FTR_ERR_LAUNCH;
   }
   if (dirty_host) {   // diagnostic: non-zero words of the hand-off region apart from the status word (must be 0 between launches)
-    const size_t n = l.total - l.ctrl_off;
+    const size_t n = l.total - l.ctrl_off - 4;   // everything but the status block
     unsigned* h = static_cast<unsigned*>(malloc(n * sizeof(unsigned)));
     if (!h || hipMemcpyAsync(h, ws + l.ctrl_off, n * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
       free(h); (void)hipGetLastError(); set_error("mutual_information_status: copy failed"); return FTR_ERR_LAUNCH;
     }
     long long cnt = 0;
-    for (size_t i = 1; i < n; ++i) cnt += (h[i] != 0);
+    for (size_t i = 0; i < n; ++i) cnt += (h[i] != 0);
     free(h);
     *dirty_host = cnt;
   }
@@ -1562,7 +1578,7 @@ int mi_bidir_status(const float* ws, size_t ws_floats, int B, int S, int T, int*
 
 int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, size_t ws_floats, int flags,
                  float* ans, int B, int S, int T, int modified, hipStream_t st) {
-  const BidirLayout l = bidir_layout(B, S, T);
+  const BidirLayout l = anchored(bidir_layout(B, S, T), ws_floats);
   int rc = check_ws("mutual_information_fwd", ws, ws_floats, l);
   if (rc != FTR_OK) return rc;
   if (l.Tg / CH >= (int)kTagChunkMask) { set_error("mutual_information_fwd: T = %d is beyond the %u chunks a granule tag can number", T, kTagChunkMask); return FTR_ERR_UNSUPPORTED; }
@@ -1578,14 +1594,14 @@ int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, floa
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ws + l.cxy_off, reinterpret_cast<int*>(ws + l.phi_off), ctrl, ans, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ws + l.cxy_off, reinterpret_cast<int*>(ws + l.phi_off), ctrl, ans, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_fwd_kernel<true>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ws + l.cxy_off, reinterpret_cast<int*>(ws + l.phi_off), ctrl, (int)(status_off(l) - l.ctrl_off), ans, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_fwd_kernel<false>, grid, dim3(256), lds, st, px, py, boundary, ws, gran, ws + l.pmid_off, ws + l.occ_off, ws + l.cxy_off, reinterpret_cast<int*>(ws + l.phi_off), ctrl, (int)(status_off(l) - l.ctrl_off), ans, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_fwd");
 }
 
 int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int flags, float* px_grad, float* py_grad,
                  float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st) {
-  const BidirLayout l = bidir_layout(B, S, T);
+  const BidirLayout l = anchored(bidir_layout(B, S, T), ws_floats);
   int rc = check_ws("mutual_information_bwd", ws, ws_floats, l);
   if (rc != FTR_OK) return rc;
   float* wsm = const_cast<float*>(ws);   // seed snapshot, ctrl and the flow granules are scratch
@@ -1614,8 +1630,8 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl, B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl + (status_off(l) - l.ctrl_off), B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl + (status_off(l) - l.ctrl_off), B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
 }
 

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "ftr_set_mi_impl": (ctypes.c_int, [_i]),
     "ftr_get_mi_impl": (ctypes.c_int, []),
     "ftr_mutual_information_workspace_floats": (ctypes.c_size_t, [_i, _i, _i]),
+    "ftr_mutual_information_handoff_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "ftr_mutual_information_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_bwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_fwd_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, ctypes.c_size_t, _i, _c_fp, _i, _i, _i, _i, _c_st]),
@@ -65,6 +66,7 @@ _SIGNATURES = {
     "ftr_simple_logprobs_fused_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_fused_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _f, _f, _c_fp, _c_fp, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_band_supported": (_i, [_i, _i, _i]),
+    "ftr_band_ranges_check_i32": (_i, [_c_ip, _c_ip, _c_ip, _i, _i, _i, _c_st]),
     "ftr_pruned_band_fwd_f32": (_i, [_c_fp, _c_ip, _c_ip, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_band_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_band_workspace_floats": (ctypes.c_size_t, [_i, _i, _i, _i]),

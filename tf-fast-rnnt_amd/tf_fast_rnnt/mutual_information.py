@@ -51,34 +51,75 @@ def _as_boundary(boundary, B: int, device) -> Optional[torch.Tensor]:
 
 
 class _Workspace:
-    """One cached fwd->bwd workspace per (device, stream, B, S, T): allocated and initialised
-    (ftr_mutual_information_workspace_init) once, then handed to every launch with FTR_MI_WS_CLEAN -- the launches leave
-    the hand-off region clean, so no memset node is needed.  Safe because every user of the workspace in this package
-    runs the forward and the backward launch back to back on one stream (the occupancies, not the workspace, are what
-    autograd keeps).  Under stream capture the cache is bypassed (a graph owns its allocations)."""
+    """ONE cached forward->backward workspace per (device, stream), sized by CAPACITY, not by shape: a training loop pads
+    every batch to its own maximum, so (B, S, T) change from step to step and a cache keyed on the exact shape would
+    allocate and initialise a workspace per step.  The native layout anchors the hand-off region of a launch at the END of
+    the buffer it is given and grows everything else from the front (include/ftr.h, FTR_MI_WS_CLEAN), so one buffer of
+    (largest data part seen) + (largest hand-off part seen) floats serves every shape seen so far; its tail is zeroed when
+    the buffer is (re)allocated -- on growth only -- and every launch leaves its hand-off region zero again, so every
+    launch gets FTR_MI_WS_CLEAN and no memset node.  Safe because every user of the workspace in this package runs the
+    forward and the backward launch back to back on one stream (the occupancies, not the workspace, are what autograd
+    keeps).  Under stream capture the cache is bypassed (a graph owns its allocations).
+
+    If a launch ever times out waiting for a producer (ftr_mutual_information_status bit 0: cannot happen unless a
+    workgroup never ran) its `ans` is NaN and the hand-off region is left dirty: call ``clear_workspace_cache()`` (or
+    ``check_workspace_status()``, which synchronises, reads the status word and drops the dirty buffers)."""
     _cache = {}
+    inits = 0      # (re)allocations so far: the tests assert that a ragged loop does not allocate per step
+
+    def __init__(self):
+        self.ws = None; self.cap = 0; self.data_max = 0; self.handoff_max = 0; self.last = None
 
     @classmethod
     def get(cls, L, device, B, S, T):
         st = torch.cuda.current_stream(device)
+        total = L.ftr_mutual_information_workspace_floats(B, S, T)
         if torch.cuda.is_current_stream_capturing():
-            n = L.ftr_mutual_information_workspace_floats(B, S, T)
-            return torch.empty(n, dtype=torch.float32, device=device), n, 0
-        key = (device.index, st.cuda_stream, B, S, T)
-        hit = cls._cache.get(key)
-        if hit is None:
-            if len(cls._cache) >= 8:           # a training loop has a handful of shapes; do not hoard HBM beyond that
+            return torch.empty(total, dtype=torch.float32, device=device), total, 0
+        key = (device.index, st.cuda_stream)
+        w = cls._cache.get(key)
+        if w is None:
+            if len(cls._cache) >= 4:           # a handful of (device, stream) pairs; do not hoard HBM beyond that
                 cls._cache.pop(next(iter(cls._cache)))
-            n = L.ftr_mutual_information_workspace_floats(B, S, T)
-            ws = torch.empty(n, dtype=torch.float32, device=device)
-            _lib.call("ftr_mutual_information_workspace_init", ws.data_ptr(), n, B, S, T, st.cuda_stream)
-            hit = cls._cache[key] = (ws, n)
-        return hit[0], hit[1], _lib.FTR_MI_WS_CLEAN
+            w = cls._cache[key] = _Workspace()
+        handoff = L.ftr_mutual_information_handoff_floats(B, S, T)
+        data = total - handoff
+        if w.ws is None or data > w.data_max or handoff > w.handoff_max:
+            # grow with some headroom so that a slowly rising maximum does not reallocate every few steps
+            w.data_max = max(w.data_max, data + data // 8 if w.ws is not None else data)
+            w.handoff_max = max(w.handoff_max, handoff + handoff // 8 if w.ws is not None else handoff)
+            w.cap = w.data_max + w.handoff_max + 8
+            w.ws = None                        # release before allocating the larger one
+            w.ws = torch.empty(w.cap, dtype=torch.float32, device=device)
+            w.ws[w.cap - w.handoff_max - 8:].zero_()     # every shape's hand-off region lies inside this tail
+            cls.inits += 1
+        w.last = (B, S, T)
+        return w.ws, w.cap, _lib.FTR_MI_WS_CLEAN
 
 
 def clear_workspace_cache() -> None:
     """Drops the cached recursion workspaces (they are re-created on demand)."""
     _Workspace._cache.clear()
+
+
+def check_workspace_status() -> int:
+    """Synchronises and reads the sticky status word of every cached workspace (ftr_mutual_information_status): returns
+    the OR of them and drops the workspaces that report a problem, so that the next launch starts from a clean one.
+    0 = fine.  Diagnostic: a non-zero value means a launch gave up waiting for a producer and answered NaN."""
+    import ctypes
+    L = _lib.lib()
+    bad = 0
+    for key, w in list(_Workspace._cache.items()):
+        if w.ws is None or w.last is None:
+            continue
+        B, S, T = w.last
+        st = ctypes.c_int(-1)
+        with torch.cuda.device(w.ws.device):
+            _lib.call("ftr_mutual_information_status", w.ws.data_ptr(), w.cap, B, S, T, ctypes.byref(st), None, key[1])
+        if st.value != 0:
+            bad |= st.value
+            del _Workspace._cache[key]
+    return bad
 
 
 def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[torch.Tensor],

@@ -369,7 +369,7 @@ def rnnt_loss_simple(
 def _identity_ranges(B: int, T: int, S1: int, device) -> torch.Tensor:
     """ranges[b,t,:] = 0..S: with every row in range the pruned builder IS the joint builder (its band is the lattice)."""
     ranges = torch.arange(S1, dtype=torch.int32, device=device).expand(B, T, S1).contiguous()
-    ranges._ftr_monotone = True
+    _mark_band(ranges)
     return ranges
 
 
@@ -472,10 +472,10 @@ def get_rnnt_prune_ranges(
                                                    _ptr(scratch), B, S, T, T1, s_range, ctypes.byref(r_eff),
                                                    _stream_ptr(px_grad))
     assert r_eff.value == r
-    # what the kernel guarantees (rnnt_loss.py:673-677): ranges[b,t,0] non-decreasing in t, inside [0, S - r + 1].
-    # rnnt_loss_pruned runs the recursion on the band itself for ranges that carry this mark (ftr_mutual_information_band_f32)
-    # and on full-size lattices for any other ranges tensor.
-    ranges._ftr_monotone = True
+    # what the kernel guarantees (rnnt_loss.py:673-677): ranges[b,t,0] non-decreasing in t, inside [0, S - r + 1], and
+    # ranges[b,t,k] = ranges[b,t,0] + k: a band.  The mark only saves rnnt_loss_pruned the device-side check it runs on
+    # ranges tensors it has not seen (a clone, a slice, a reloaded tensor: _is_band).
+    _mark_band(ranges)
     return ranges
 
 
@@ -574,8 +574,8 @@ def _pruned_inputs(logits, symbols, ranges, boundary):
     symbols = torch.as_tensor(symbols, device=logits.device).to(torch.int32).contiguous()
     ranges_in = ranges
     ranges = torch.as_tensor(ranges, device=logits.device).to(torch.int32).contiguous()
-    if ranges is not ranges_in and getattr(ranges_in, "_ftr_monotone", False):
-        ranges._ftr_monotone = True      # a dtype / layout / device copy of marked ranges is still monotone
+    if ranges is not ranges_in and isinstance(ranges_in, torch.Tensor) and _band_mark_valid(ranges_in):
+        _mark_band(ranges)      # a dtype / layout / device copy of a known band is still a band
     if tuple(ranges.shape) != (B, T, r):
         raise ValueError(f"ranges must have shape {(B, T, r)}, got {tuple(ranges.shape)}")
     if symbols.dim() != 2 or symbols.shape[0] != B:
@@ -603,11 +603,47 @@ def get_rnnt_logprobs_pruned(
     return px, py
 
 
-def _band_path_ok(ranges, T: int, S: int, r: int) -> bool:
-    """The band-native recursion needs monotone ranges (only get_rnnt_prune_ranges' own output is known to be) and a band
-    that fits its LDS-resident kernel."""
-    return bool(getattr(ranges, "_ftr_monotone", False)) and \
-        _lib.lib().ftr_mutual_information_band_supported(int(T), int(S), int(r)) != 0
+def _mark_band(ranges: torch.Tensor) -> None:
+    """Remembers on the tensor object that its CURRENT contents are a band (the version counter catches in-place edits)."""
+    ranges._ftr_band = ranges._version
+
+
+def _band_mark_valid(ranges: torch.Tensor) -> bool:
+    return getattr(ranges, "_ftr_band", None) == ranges._version
+
+
+def _is_band(ranges: torch.Tensor, boundary) -> bool:
+    """Are these ranges what the band-native kernels assume (ranges[b,t,0] non-decreasing over the frames of each boundary
+    rectangle, ranges[b,t,k] = ranges[b,t,0] + k)?  Decided by the DATA: a tensor that carries no valid mark (anything but
+    the output of get_rnnt_prune_ranges itself: a clone, a slice, a .to(), a checkpoint) is checked once on the device
+    (ftr_band_ranges_check_i32, one small kernel and one host read of its flag word) and the verdict is remembered on the
+    tensor, so only the first use of an unknown tensor synchronises.  Under stream capture an unknown tensor takes the
+    lattice route (no host read inside a capture)."""
+    if _band_mark_valid(ranges):
+        return True
+    if getattr(ranges, "_ftr_not_band", None) == ranges._version:
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    B, T, r = ranges.shape
+    flags = torch.empty((1,), dtype=torch.int32, device=ranges.device)
+    with torch.cuda.device(ranges.device):
+        _lib.call("ftr_band_ranges_check_i32", _ptr(ranges), _ptr(boundary), _ptr(flags), B, T, r, _stream_ptr(ranges))
+    ok = int(flags.item()) == 0
+    if ok:
+        _mark_band(ranges)
+    else:
+        ranges._ftr_not_band = ranges._version
+    return ok
+
+
+def _band_path_ok(ranges, boundary, T: int, S: int, r: int) -> bool:
+    """The band-native recursion needs a band that its kernels cover (r <= 15) and ranges that ARE a band (_is_band).
+    FTR_PRUNED_ROUTE=lattice (a test knob, read at call time) sends everything through the full-size lattices."""
+    import os
+    if os.environ.get("FTR_PRUNED_ROUTE") == "lattice":
+        return False
+    return _lib.lib().ftr_mutual_information_band_supported(int(T), int(S), int(r)) != 0 and _is_band(ranges, boundary)
 
 
 class _PrunedLoss(torch.autograd.Function):
@@ -628,7 +664,7 @@ class _PrunedLoss(torch.autograd.Function):
         x = logits.detach().contiguous()
         need = logits.requires_grad
         lse = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
-        ctx.band = _band_path_ok(ranges, T, S, r)
+        ctx.band = _band_path_ok(ranges, boundary, T, S, r)
         if ctx.band:
             pxb = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
             pyb = torch.empty((B, T, r), dtype=torch.float32, device=x.device)
