@@ -60,7 +60,8 @@ def make_inputs(B, T, S, C, seed, device, ragged=False):
     return dict(am=am, lm=lm, symbols=symbols, boundary=boundary.to(device), blank=C - 1, B=B, T=T, S=S, C=C)
 
 
-def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5, first_pass="simple", process_group=None, timer=None):
+def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5, first_pass="simple", process_group=None, timer=None,
+                dense_am_pruned=False):
     """One full step of the hot path (see module docstring).  Returns the scalar loss (and internals).
     first_pass = "smoothed" uses rnnt_loss_smoothed (lm_only_scale 0.1, am_only_scale 0.2 as in
     simple_rnnt_loss_test.py:291-336) for the occupancy pass (BASELINE.json configs[3], "c4")."""
@@ -77,7 +78,7 @@ def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5, first_pass="sim
         simple_loss, (px_grad, py_grad) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=sym, termination_symbol=blank,
                                                              boundary=bd, reduction="sum", calc_gradients=True)
     ranges = ft.get_rnnt_prune_ranges(px_grad=px_grad, py_grad=py_grad, boundary=bd, s_range=s_range)
-    am_p, lm_p = ft.do_rnnt_pruning(am=am, lm=lm, ranges=ranges)
+    am_p, lm_p = ft.do_rnnt_pruning(am=am, lm=lm, ranges=ranges, dense=dense_am_pruned)
     if timer is not None and timer.enabled:       # the joiner stand-in is user code, timed apart from the loss
         with timer("joiner_standin_fwd"):
             logits = torch.sigmoid(am_p + lm_p)
@@ -97,6 +98,20 @@ def pruned_step(inp, s_range, keep=False, simple_loss_scale=0.5, first_pass="sim
         return dict(loss=loss.detach(), simple_loss=simple_loss.detach(), pruned_loss=pruned_loss.detach(),
                     ranges=ranges, px_grad=px_grad, py_grad=py_grad, logits_grad=logits.grad,
                     am_grad=am.grad, lm_grad=lm.grad)
+    return loss.detach()
+
+
+def simple_step(inp, keep=False, timer=None):
+    """BASELINE.json configs[1] ("c2"): rnnt_loss_simple forward + backward only -- px/py builder, recursion forward and
+    backward (occupancies), and the builder's backward to d am, d lm."""
+    import tf_fast_rnnt as ft
+    am = inp["am"].detach().requires_grad_(True)
+    lm = inp["lm"].detach().requires_grad_(True)
+    loss, (px_grad, py_grad) = ft.rnnt_loss_simple(lm=lm, am=am, symbols=inp["symbols"], termination_symbol=inp["blank"],
+                                                   boundary=inp["boundary"], reduction="sum", calc_gradients=True)
+    loss.backward()
+    if keep:
+        return dict(loss=loss.detach(), px_grad=px_grad, py_grad=py_grad, am_grad=am.grad, lm_grad=lm.grad)
     return loss.detach()
 
 
@@ -229,7 +244,7 @@ def algorithmic_bytes(B, T, S, C, r):
 def _cpu_pipeline_worker(job):
     """One worker of the CPU baseline: the oracle's whole loss pipeline on batches of `sample_B` utterances of the
     workload, single-threaded, repeated until `seconds` have passed.  Returns (utterances done, seconds)."""
-    B, T, S, C, r, sample_B, seed, seconds = job
+    B, T, S, C, r, sample_B, seed, seconds, simple_only = job
     os.environ["OMP_NUM_THREADS"] = "1"
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rnnt_oracle as O
@@ -249,6 +264,12 @@ def _cpu_pipeline_worker(job):
         t0 = time.perf_counter()
         while True:
             _, (gx, gy) = O.rnnt_loss_simple(lm, am, sym, C - 1, bd, reduction="sum", calc_gradients=True)
+            if simple_only:
+                done += sample_B
+                dt = time.perf_counter() - t0
+                if dt >= seconds or done >= 4096:
+                    break
+                continue
             ranges = O.get_rnnt_prune_ranges(gx, gy, bd, r)
             am_p, lm_p = O.do_rnnt_pruning(am, lm, ranges)
             logits = (1.0 / (1.0 + np.exp(-(am_p + lm_p)))).astype(np.float32)
@@ -277,14 +298,16 @@ def _host_description():
     return dict(nproc=os.cpu_count(), usable_cores=usable, cpu_model=model)
 
 
-def cpu_baseline(B, T, S, C, r, sample_B=4, seed=0, seconds=9.0, max_workers=16):
+def cpu_baseline(B, T, S, C, r, sample_B=4, seed=0, seconds=9.0, max_workers=16, simple_only=False):
     """SURVEY.md 8(d) CPU baseline: the oracle (CPU port of the same path: px/py builder + recursion fwd+bwd + ranges +
-    gather + sigmoid + pruned log-probs + recursion fwd+bwd + gradient w.r.t. logits) timed on this host, (i) on one
-    thread and (ii) on all usable cores, parallel over the batch dimension (one single-threaded worker process per
-    core, each on its own utterances).  `value` is the all-cores rate; the single-thread rate is reported beside it."""
+    gather + sigmoid + pruned log-probs + recursion fwd+bwd + gradient w.r.t. logits; simple_only: the first of these)
+    timed on this host, (i) on one thread and (ii) on `cores` single-threaded worker processes, parallel over the batch
+    dimension, each on its own utterances.  cores = min(usable cores, 16): 16 is the CPU share of one GPU on the pool's
+    boxes (a box reports 256 cores for 8 GPUs), and what `cpu_baseline.cores` states is the number actually used.
+    `value` is the multi-worker rate; the single-thread rate is reported beside it."""
     import multiprocessing as mp
     host = _host_description()
-    one_done, one_dt = _cpu_pipeline_worker((B, T, S, C, r, sample_B, seed, seconds))
+    one_done, one_dt = _cpu_pipeline_worker((B, T, S, C, r, sample_B, seed, seconds, simple_only))
     single = one_done / one_dt
     workers = max(1, min(host["usable_cores"], max_workers))
     multi = None
@@ -292,7 +315,7 @@ def cpu_baseline(B, T, S, C, r, sample_B=4, seed=0, seconds=9.0, max_workers=16)
         ctx = mp.get_context("spawn")     # fresh interpreters: the parent holds a HIP context
         with ctx.Pool(workers) as pool:
             t0 = time.perf_counter()
-            res = pool.map(_cpu_pipeline_worker, [(B, T, S, C, r, sample_B, seed + 1 + i, seconds) for i in range(workers)])
+            res = pool.map(_cpu_pipeline_worker, [(B, T, S, C, r, sample_B, seed + 1 + i, seconds, simple_only) for i in range(workers)])
             wall = time.perf_counter() - t0
         # every worker runs for >= `seconds` after its own start-up; rate = sum of the workers' own rates
         multi = sum(d / t for d, t in res)
@@ -300,8 +323,10 @@ def cpu_baseline(B, T, S, C, r, sample_B=4, seed=0, seconds=9.0, max_workers=16)
     value = multi if multi is not None else single
     return dict(value=round(value, 3), unit="utterances/s", cores=workers, kind="port",
                 single_thread_value=round(single, 3), host=host,
-                sample=f"the oracle's whole loss pipeline (oracle/: C recursion + numpy builders; forward + gradients w.r.t. "
-                       f"px/py and pruned logits, without the autograd tail to am/lm) on batches of {sample_B} utterances of "
+                sample=("the oracle's rnnt_loss_simple with occupancies (oracle/: numpy builder + C recursion forward + backward, "
+                        "without the builder's backward to am/lm)" if simple_only else
+                        "the oracle's whole loss pipeline (oracle/: C recursion + numpy builders; forward + gradients w.r.t. "
+                        "px/py and pruned logits, without the autograd tail to am/lm)") + f" on batches of {sample_B} utterances of "
                        f"the same workload: 1 thread {one_done} utterances in {one_dt:.1f} s; "
                        + (f"{workers} single-threaded worker processes, {multi_done} utterances, {wall:.1f} s wall incl. start-up"
                           if multi is not None else "one usable core only"))
@@ -338,15 +363,35 @@ def graph_replay(step_fn, steps):
 
 
 # ------------------------------------------------------------------------------------------------ self-launch
+def visible_gpu_count() -> int:
+    """GPUs this process could use, counted WITHOUT any HIP / HSA call (the launching parent must never initialise the
+    GPU): the KFD topology in sysfs lists one node per agent, GPU nodes have simd_count > 0; ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES restrict it the way the runtime would."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N rank processes (fresh children, one device each, RCCL),
-    rank 0 prints the JSON line.  The parent never touches the GPU (torch.cuda.device_count() does not initialise it
-    on this image) and never re-execs itself.  Returns the exit code."""
+    rank 0 prints the JSON line.  The parent never touches the GPU (devices are counted from sysfs, visible_gpu_count)
+    and never re-execs itself.  Returns the exit code."""
     import socket
     import subprocess
     n = args.gpus
     forced = "FTR_BENCH_FORCE_DEVICE" in os.environ      # rehearsal: every rank on one card (gloo backend)
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if not forced and have < n:
         print(f"bench.py: --gpus {n} asked for but only {have} HIP device(s) are visible; not measuring fewer GPUs "
               f"under an n_gpus={n} label", file=sys.stderr)
@@ -385,6 +430,9 @@ def main():
     ap.add_argument("--no-gemm-search", action="store_true", help="only apply the choices already in --gemm-choices (profiling runs)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="record the per-call HIP events on every n-th timed step (1 = every step)")
+    ap.add_argument("--pass", dest="which", default=None, choices=["pipeline", "simple"],
+                    help="pipeline = the whole pruned step (default); simple = rnnt_loss_simple forward + backward only "
+                         "(BASELINE.json configs[1]; the default for --config c2)")
     ap.add_argument("--first-pass", default=None, choices=["simple", "smoothed"],
                     help="occupancy pass; default simple, smoothed for c4 (BASELINE.json configs[3])")
     args = ap.parse_args()
@@ -418,10 +466,14 @@ def main():
 
     timer = CallTimer()
     first_pass = args.first_pass or ("smoothed" if args.config == "c4" else "simple")
+    which = args.which or ("simple" if args.config == "c2" else "pipeline")
     group = dist.group.WORLD if (dist is not None and first_pass == "smoothed") else None
 
-    def step():
-        loss = pruned_step(inp, r, first_pass=first_pass, process_group=group, timer=timer)
+    def step(dense=False):
+        if which == "simple":
+            loss = simple_step(inp, timer=timer)
+        else:
+            loss = pruned_step(inp, r, first_pass=first_pass, process_group=group, timer=timer, dense_am_pruned=dense)
         if dist is not None:
             dist.all_reduce(loss)           # the single scalar exchange of the sharded loss
         return loss
@@ -456,6 +508,18 @@ def main():
     timer.enabled = False
     ft._lib.set_profile_hook(None)
     peak_mb = torch.cuda.max_memory_allocated(dev) / 2**20
+    # secondary: the same step with am_pruned MATERIALISED ([B,T,r,C] written by the gather and read by the joiner), which is
+    # what the reference's tf.broadcast_to costs and what a TensorFlow binding of the C ABI pays; untimed for `value`
+    dense_ms = None
+    if which == "pipeline" and world == 1:
+        for _ in range(2):
+            step(dense=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(args.steps // 2, 1)):
+            step(dense=True)
+        torch.cuda.synchronize()
+        dense_ms = 1e3 * (time.perf_counter() - t1) / max(args.steps // 2, 1)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -501,8 +565,14 @@ def main():
     tot_us = sum(calls[n]["total_ms"] for n in calls if n in alg) * 1e3 / len(sampled)
     joiner_us = sum(calls[n]["total_ms"] for n in calls if n.startswith("joiner_standin")) * 1e3 / len(sampled)
     native_us = sum(rec["total_ms"] for n, rec in calls.items() if not n.startswith("joiner_standin")) * 1e3 / len(sampled)
+    if which == "simple":
+        workload = (f"{args.config}: rnnt_loss_simple fwd+bwd (builder + recursion forward/backward + builder backward to am, lm), "
+                    f"B={B}/GPU T={T} S={S} C={C}, regular, {'ragged' if args.ragged else 'full'} boundary")
+    else:
+        workload = (f"{args.config}: rnnt_loss_pruned fwd+bwd step, B={B}/GPU T={T} S={S} C={C} s_range={r}, "
+                    f"regular, {'ragged' if args.ragged else 'full'} boundary, first pass rnnt_loss_{first_pass}")
     out = {
-        "metric": "rnnt_loss_pruned_fwd_bwd_throughput",
+        "metric": "rnnt_loss_simple_fwd_bwd_throughput" if which == "simple" else "rnnt_loss_pruned_fwd_bwd_throughput",
         "value": round(value, 2),
         "unit": "utterances/s",
         "n_gpus": world,
@@ -516,8 +586,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.config}: rnnt_loss_pruned fwd+bwd step, B={B}/GPU T={T} S={S} C={C} s_range={r}, "
-                               f"regular, {'ragged' if args.ragged else 'full'} boundary, first pass rnnt_loss_{first_pass}",
+        "config": {"workload": workload,
                    "global_batch": world * B, "sharding": f"batch x{world}, one scalar all-reduce/step",
                    # do_rnnt_pruning returns am_pruned as a stride-0 broadcast view of am (values, shape and gradient as the
                    # reference's tf.broadcast_to; the reference's joiner stand-in consumes it by broadcasting)
@@ -533,17 +602,18 @@ def main():
         "native_aggregate": {"algorithmic_MB_per_step": round(tot_alg / 1e6, 1), "us_per_step": round(tot_us, 1),
                              "GBps": round(tot_alg / (tot_us * 1e-6) / 1e9, 1) if tot_us > 0 else None,
                              "frac_of_peak": round(tot_alg / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if tot_us > 0 else None},
+        "dense_am_pruned_ms_per_step": round(dense_ms, 4) if dense_ms is not None else None,
         "kernels": kernels,
         "loss": float(last.item()),
         "gemm_tuning": not args.no_gemm_tuning,
     }
     if world == 1 and not args.no_graph:
-        gr = graph_replay(lambda: pruned_step(inp, r, first_pass=first_pass), args.steps)
+        gr = graph_replay((lambda: simple_step(inp)) if which == "simple" else (lambda: pruned_step(inp, r, first_pass=first_pass)), args.steps)
         if gr.get("ms_per_step"):
             gr["value"] = round(B / (gr["ms_per_step"] * 1e-3), 2)
         out["graph_replay"] = gr
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(B, T, S, C, r)
+        out["cpu_baseline"] = cpu_baseline(B, T, S, C, r, simple_only=(which == "simple"))
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -39,14 +39,6 @@ int ftr_abi_version(void);
 const char* ftr_package_version(void);
 /* Thread-local description of the last non-success return on this thread ("" if none). */
 const char* ftr_last_error(void);
-/* Selects the mutual-information kernel family: 0 = "wavefront" (default: skewed wave64 DP, one workgroup per
- * 64-row band, bands chained through tagged granules, the recursion run from both ends of the lattice towards a
- * cut in the middle; mi_wave_bidir.hip), 1 = "plain" (one thread per lattice row, the reference's arithmetic on the
- * device, up to 1024 rows: a bisecting aid, not a product path).  Also settable with FTR_MI_IMPL=wavefront|plain.
- * Returns the previous value. */
-int ftr_set_mi_impl(int impl);
-int ftr_get_mi_impl(void);
-
 /* Number of floats of fwd->bwd workspace (`p` below) for a problem size.  `p` is NOT the reference's [B,S+1,T+1] temp
  * (tf_fast_rnnt_op.cc:65-67): it is about TWO lattices of that shape (one split-ratio lattice per direction of the
  * recursion), the values on the cut, and an inter-workgroup hand-off region -- a buffer of B*(S+1)*(T+1) floats is too
@@ -402,17 +394,6 @@ int ftr_pruned_band_bwd_scaled_f32(const float* logits, const int32_t* symbols, 
  * 16-byte global loads/stores at 4-byte alignment).  scratch_dev: >= 8 KiB of device memory; after the
  * stream has drained, ((int*)scratch_dev)[0] == 1 means pass. */
 int ftr_selftest(void* scratch_dev, void* stream);
-
-/* Diagnostic: copies 16 counters out of the library (host pointer).  All zero unless the library was built
- * with `make STAMPS=1`, in which case they are per-segment s_memtime sums of the wavefront kernels'
- * steady-state slot ([0..5] forward, [8..13] backward: compute, refill tile, issue stores, issue loads,
- * barrier, slots counted).  Synchronises the device. */
-int ftr_debug_stamps(unsigned long long* out16);
-/* Diagnostic: copies n <= 1024 words of the kernel timeline out of the library (host pointer) and re-arms it.  All zero
- * unless the library was built with -DFTR_TRACE=1 (forward) or =2 (flow): [0] earliest workgroup start, [1] latest
- * workgroup end, [2]/[3] start/end of one traced workgroup, [4] slots recorded, [16+k] its slot times, in 100 MHz ticks.
- * Synchronises the device. */
-int ftr_debug_trace(unsigned long long* out, int n);
 
 #ifdef __cplusplus
 }

@@ -8,10 +8,9 @@ import tf_fast_rnnt as ft
 from tf_fast_rnnt import _lib
 from tf_fast_rnnt.mutual_information import _ptr
 
-def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
+def run(B, S, T, iters=20, cold=False, warm=3):
     dev = torch.device("cuda:0")
     L = _lib.lib()
-    L.ftr_set_mi_impl(impl)
     g = torch.Generator(device="cpu").manual_seed(0)
     px = (torch.randn((B, S, T + 1), generator=g) - 6.0).to(dev)
     py = (torch.randn((B, S + 1, T), generator=g) - 6.0).to(dev)
@@ -21,8 +20,8 @@ def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
     nws = L.ftr_mutual_information_workspace_floats(B, S, T)
     ws = torch.empty(nws, dtype=torch.float32, device=dev)
     _lib.call("ftr_mutual_information_workspace_init", _ptr(ws), nws, B, S, T, torch.cuda.current_stream().cuda_stream)
-    product = impl == 0 and not os.environ.get("FTR_BENCH_LEGACY_CALLS")   # what the package does: clean cached workspace, seed = ones
-    pg = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=dev) if impl == 1 else None
+    product = not os.environ.get("FTR_BENCH_LEGACY_CALLS")   # what the package does: clean cached workspace, seed = ones
+    pg = None
     ans = torch.empty(B, device=dev); ag = torch.ones(B, device=dev)
     gx = torch.empty_like(px); gy = torch.empty_like(py)
     st = torch.cuda.current_stream().cuda_stream
@@ -62,7 +61,6 @@ def run(B, S, T, iters=20, impl=0, cold=False, warm=3):
         torch.cuda.synchronize()
         if i >= warm:
             tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
-    L.ftr_set_mi_impl(0)
     cells = B * (S + 1) * (T + 1)
     return 1e3 * tf / iters, 1e3 * tb / iters, cells
 
@@ -75,11 +73,10 @@ if __name__ == "__main__":
             f, b, cells = run(B, S, T, cold=cold)
             nslots = ((T + 1 + 63 + 15) // 16) + 5 * ((S + 1 + 63) // 64 - 1)
             print(f"B={B:4d} S={S:5d} T={T:5d} {'cold' if cold else 'warm'}: fwd {f:8.1f} us ({12*cells/f/1e3:7.1f} GB/s alg, {f/nslots*1e3:6.0f} ns/slot)   bwd {b:8.1f} us ({20*cells/b/1e3:7.1f} GB/s alg, {b/nslots*1e3:6.0f} ns/slot)", flush=True)
-    f, b, cells = run(32, 200, 1000, impl=1)
-    print(f"plain family B=32 S=200 T=1000: fwd {f:.1f} us  bwd {b:.1f} us")
     import ctypes
     buf = (ctypes.c_ulonglong * 16)()
-    _lib.lib().ftr_debug_stamps(buf)
+    if hasattr(_lib.lib(), "ftr_debug_stamps"):      # a diag-flavoured build (FTR_LIB_PATH=.../libftr_<variant>.so)
+        _lib.lib().ftr_debug_stamps(buf)
     v = list(buf)
     if any(v):
         # duo kernels: [0..2] fwd compute wave (compute, barrier wait, slots), [3..7] fwd IO wave (park, drain, loads, barrier, slots)

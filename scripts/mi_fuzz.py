@@ -1,17 +1,17 @@
 """Randomised comparison of the wavefront recursion (product) with the plain one-thread-per-row kernels (reference
-arithmetic on the device, ftr_set_mi_impl(1)): shapes, ragged boundaries with begin offsets, both types, -inf entries.
+arithmetic on the device, from the test-only diag library: tests/diag.py): shapes, ragged boundaries with begin offsets, both types, -inf entries.
 python scripts/mi_fuzz.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tf-fast-rnnt_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tf-fast-rnnt_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import tf_fast_rnnt as ft
-from tf_fast_rnnt import _lib
+import diag
 
 
 def main(n=100, seed=0):
     rng = np.random.default_rng(seed)
-    dev = torch.device("cuda:0"); L = _lib.lib()
+    dev = torch.device("cuda:0")
     worst = 0.0
     for it in range(n):
         B = int(rng.integers(1, 5)); S = int(rng.choice([0, 1, 2, 5, 17, 63, 64, 65, 100, 130, 200, 257])); T = int(rng.choice([1, 2, 3, 15, 16, 17, 40, 64, 100, 130, 257, 500]))
@@ -28,14 +28,18 @@ def main(n=100, seed=0):
             bd[b] = (sb, tb, se, te)
         res = []
         for impl in (0, 1):
-            L.ftr_set_mi_impl(impl)
             tx = torch.from_numpy(px).to(dev).requires_grad_(True); ty = torch.from_numpy(py).to(dev).requires_grad_(True)
-            ans = ft.mutual_information_recursion(tx, ty, torch.from_numpy(bd).to(dev))
-            fin = torch.isfinite(ans)
-            if fin.any(): ans[fin].sum().backward()
-            gx = np.zeros_like(px) if tx.grad is None else tx.grad.cpu().numpy(); gy = np.zeros_like(py) if ty.grad is None else ty.grad.cpu().numpy()
+            if impl == 0:
+                ans = ft.mutual_information_recursion(tx, ty, torch.from_numpy(bd).to(dev))
+                fin = torch.isfinite(ans)
+                if fin.any(): ans[fin].sum().backward()
+                gx = np.zeros_like(px) if tx.grad is None else tx.grad.cpu().numpy(); gy = np.zeros_like(py) if ty.grad is None else ty.grad.cpu().numpy()
+            else:   # the gradient of the sum over the finite answers = the backward seeded with their indicator
+                ans = diag.plain_forward_backward(tx.detach(), ty.detach(), torch.from_numpy(bd).to(dev), False)[0]
+                fin = torch.isfinite(ans)
+                _, gxt, gyt, _ = diag.plain_forward_backward(tx.detach(), ty.detach(), torch.from_numpy(bd).to(dev), True, ans_grad=fin.float())
+                gx, gy = gxt.cpu().numpy(), gyt.cpu().numpy()
             res.append((ans.detach().cpu().numpy(), gx, gy, fin.cpu().numpy()))
-        L.ftr_set_mi_impl(0)
         (a0, x0, y0, f0), (a1, x1, y1, f1) = res
         assert np.array_equal(f0, f1), (it, B, S, T, mod, bd, a0, a1)
         if f0.any():

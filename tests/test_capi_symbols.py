@@ -10,8 +10,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ftr.h")).read()
+def _declared_symbols(header="ftr.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ftr_\w+)\s*\(", text)))
 
@@ -23,6 +23,21 @@ def test_header_symbols_are_exported(ft):
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/ftr.h but not exported by libftr_hip.so"
     assert set(names) == set(ft._lib.EXPORTED_SYMBOLS), "python binding and header disagree"
+
+
+def test_product_library_carries_no_diagnostics(ft):
+    """The switchable "plain" kernel family and the trace read-out live in the test-only diag library
+    (include/ftr_diag.h, csrc/_build/libftr_hip_diag.so), not in what ships."""
+    diag = [n for n in _declared_symbols("ftr_diag.h") if n not in _declared_symbols()]
+    assert set(diag) == {"ftr_set_mi_impl", "ftr_get_mi_impl", "ftr_debug_stamps", "ftr_debug_trace"}
+    handle = ctypes.CDLL(ft._lib.LIB_PATH)
+    for n in diag:
+        assert not hasattr(handle, n), f"{n} is exported by the product library"
+    path = os.path.join(ROOT, "tf-fast-rnnt_amd", "csrc", "_build", "libftr_hip_diag.so")
+    if os.path.exists(path):
+        d = ctypes.CDLL(path)
+        for n in diag + _declared_symbols():
+            assert hasattr(d, n), f"{n} missing from the diag library"
 
 
 def test_version_and_names(ft):
@@ -48,7 +63,8 @@ def test_signatures_match_reference_keywords(ft):
                                                "am_only_scale", "boundary", "rnnt_type", "delay_penalty", "reduction",
                                                "calc_gradients"]                                  # rnnt_loss.py:1370-1382
     assert sig(ft.get_rnnt_prune_ranges) == ["px_grad", "py_grad", "boundary", "s_range"]          # rnnt_loss.py:648-653
-    assert sig(ft.do_rnnt_pruning) == ["am", "lm", "ranges"]                                       # rnnt_loss.py:764-766
+    assert sig(ft.do_rnnt_pruning)[:3] == ["am", "lm", "ranges"]                                   # rnnt_loss.py:764-766
+    assert sig(ft.do_rnnt_pruning)[3:] == ["dense"] and inspect.signature(ft.do_rnnt_pruning).parameters["dense"].default is False
     assert sig(ft.mutual_information_recursion) == ["px", "py", "boundary", "calc_gradients"]      # __init__.py:42-47
     assert inspect.signature(ft.rnnt_loss_smoothed).parameters["lm_only_scale"].default == 0.1
     assert inspect.signature(ft.rnnt_loss_simple).parameters["reduction"].default == "mean"

@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
     from tf_fast_rnnt.distributed import reduce_loss, shard_batch
     dev = torch.device("cuda", 0)
     g = torch.Generator(device="cpu").manual_seed(77)
-    B, T, S, C, r = 6, 40, 11, 16, 4
+    B, T, S, C, r = 7, 40, 11, 16, 4          # 7 utterances over 2 ranks: uneven shards (4 + 3)
     am_f = torch.randn((B, T, C), generator=g).to(dev); lm_f = torch.randn((B, S + 1, C), generator=g).to(dev)
     sym_f = torch.randint(0, C - 1, (B, S), generator=g, dtype=torch.int32).to(dev)
     bd_f = torch.zeros((B, 4), dtype=torch.int32); bd_f[:, 2] = S; bd_f[:, 3] = T

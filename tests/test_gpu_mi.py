@@ -16,21 +16,18 @@ from helpers import assert_parity, max_rel, random_lattice
 
 pytestmark = pytest.mark.gpu
 
-IMPLS = {"wavefront": 0, "plain": 1}
-
-
 def _run(ft, dev, px, py, bd, impl, need_grads=True):
+    """impl "wavefront": the product kernels through the package; "plain": the reference's arithmetic on the device, from the
+    test-only diag library (tests/diag.py)."""
     from tf_fast_rnnt.mutual_information import mi_forward_backward
-    L = ft._lib.lib()
-    prev = L.ftr_set_mi_impl(IMPLS[impl])
-    try:
-        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if impl == "plain":
+        import diag
+        ans, gx, gy, chk = diag.plain_forward_backward(t(px), t(py), t(bd), need_grads)
+    else:
         ans, gx, gy, chk = mi_forward_backward(t(px), t(py), t(bd), need_grads, return_ans_grad_check=True)
-        torch.cuda.synchronize()
-        out = [ans.cpu().numpy()] + [None if g is None else g.cpu().numpy() for g in (gx, gy, chk)]
-    finally:
-        L.ftr_set_mi_impl(prev)
-    return out
+    torch.cuda.synchronize()
+    return [ans.cpu().numpy()] + [None if g is None else g.cpu().numpy() for g in (gx, gy, chk)]
 
 
 def test_selftest(ft, dev):
@@ -465,14 +462,9 @@ def test_absent_producer_poisons_loudly(ft, dev):
     """Test build of the library in which the first alpha band never publishes its hand-off granules
     (csrc/_build/libftr_nopublish.so, FTR_MAX_SPIN lowered): the consumer's bounded poll gives up, the launch terminates,
     the sticky status word is set and every ans is NaN -- a stalled producer cannot go unnoticed."""
-    import ctypes, os
-    from tf_fast_rnnt import _lib
-    path = os.path.join(os.path.dirname(os.path.dirname(_lib.LIB_PATH)), "csrc", "_build", "libftr_nopublish.so")
-    assert os.path.exists(path), "run __graft_entry__.build()"
-    L = ctypes.CDLL(path)
-    for name in ("ftr_mutual_information_fwd_ws_f32", "ftr_mutual_information_bwd_ws_f32", "ftr_mutual_information_status",
-                 "ftr_mutual_information_workspace_floats", "ftr_last_error"):
-        getattr(L, name).restype, getattr(L, name).argtypes = _lib._SIGNATURES[name]
+    import os
+    import diag
+    L = diag.load(os.path.join(diag.BUILD, "libftr_nopublish.so"))
     B, S, T = 3, 150, 200          # 3 bands per direction
     g = torch.Generator(device="cpu").manual_seed(2)
     px = (torch.randn((B, S, T + 1), generator=g) - 4.0).to(dev); py = (torch.randn((B, S + 1, T), generator=g) - 4.0).to(dev)

@@ -122,7 +122,7 @@ def _gloo_worker(rank, world, port, B, q):
     (y * torch.tensor([1.0, 2.0, 3.0])).sum().backward()
     # sharded smoothed builder: global unigram through the process group == single-process full batch
     g = torch.Generator().manual_seed(5)
-    Bf, T, S, C = 4, 6, 3, 5
+    Bf, T, S, C = 5, 6, 3, 5          # 5 utterances over 2 ranks: uneven shards, the mean must still be the global one
     am = torch.randn((Bf, T, C), generator=g); lm = torch.randn((Bf, S + 1, C), generator=g)
     sym = torch.randint(0, C - 1, (Bf, S), generator=g)
     l2, h2 = shard_batch(Bf, rank, world)

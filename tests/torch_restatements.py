@@ -108,7 +108,9 @@ def get_rnnt_logprobs_smoothed_torch(
     if process_group is not None:
         from tf_fast_rnnt.distributed import all_reduce_sum_differentiable
         ratio_sum = all_reduce_sum_differentiable(ratio_sum, process_group)
-        count = count * torch.distributed.get_world_size(process_group)
+        cnt = torch.tensor([count], dtype=torch.float64)      # rows of every shard (shards may be uneven)
+        torch.distributed.all_reduce(cnt, group=process_group)
+        count = float(cnt.item())
     unigram_lm = ratio_sum / count + _TINY                                    # (:1279-1280)
     amonly_normalizers = (torch.mv(am_probs.reshape(-1, C), unigram_lm.reshape(C)).log().reshape(B, T, 1) + am_max)
     amonly_normalizers = amonly_normalizers.transpose(1, 2)                   # [B,1,T]     (:1281-1286)

@@ -1,13 +1,21 @@
-// csrc/capi.hip -- the extern "C" surface declared in include/ftr.h: argument validation, kernel-family
-// selection and error reporting.  No allocation, no host synchronisation, no CPU fallback.
+// csrc/capi.hip -- the extern "C" surface declared in include/ftr.h: argument validation and error reporting.  No
+// allocation, no host synchronisation, no CPU fallback.  Built twice: into libftr_hip.so (the product: the symbols of
+// ftr.h and nothing else) and, with -DFTR_DIAG, into the test-only _build/libftr_hip_diag.so, which adds the symbols of
+// include/ftr_diag.h: the "plain" kernel family (the reference's arithmetic on the device, mi_plain.hip), its
+// process-global switch, and the read-out of the trace / stamp builds.
 #include "ftr_common.h"
+#ifdef FTR_DIAG
+#include "../../include/ftr_diag.h"
+#endif
 #include <stdlib.h>
 #include <string.h>
 
 namespace ftr {
 namespace {
 thread_local char g_err[512] = {0};
+#ifdef FTR_DIAG
 int g_mi_impl = -1;  // -1: not yet read from the environment
+#endif
 
 int device_ok() {
   int n = 0;
@@ -20,6 +28,7 @@ int device_ok() {
   return FTR_OK;
 }
 
+#ifdef FTR_DIAG
 int mi_impl() {
   if (g_mi_impl < 0) {
     const char* e = getenv("FTR_MI_IMPL");
@@ -27,6 +36,9 @@ int mi_impl() {
   }
   return g_mi_impl;
 }
+#else
+constexpr int mi_impl() { return 0; }   // the product library has one kernel family and no switch
+#endif
 }  // namespace
 
 void set_error(const char* fmt, ...) {
@@ -54,12 +66,14 @@ int ftr_abi_version(void) { return 130; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
+#ifdef FTR_DIAG
 int ftr_set_mi_impl(int impl) {
   const int prev = mi_impl();
   g_mi_impl = (impl == 1) ? 1 : 0;
   return prev;
 }
 int ftr_get_mi_impl(void) { return mi_impl(); }
+#endif
 
 size_t ftr_mutual_information_workspace_floats(int B, int S, int T) {
   if (B < 0 || S < 0 || T < 0) return 0;
@@ -85,10 +99,12 @@ int mi_fwd_common(const char* what, const float* px, const float* py, const int3
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#ifdef FTR_DIAG
   if (mi_impl() == 1) {
     FTR_REQUIRE(p_floats >= (size_t)B * (S + 1) * (T + 1), "%s: workspace too small for the plain family", what);
     return mi_plain_fwd(px, py, boundary, p, ans, B, S, T, modified, st);
   }
+#endif
   return mi_bidir_fwd(px, py, boundary, p, p_floats, flags, ans, B, S, T, modified, st);
 }
 
@@ -105,11 +121,13 @@ int mi_bwd_common(const char* what, const float* px, const float* py, const int3
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#ifdef FTR_DIAG
   if (mi_impl() == 1) {
     FTR_REQUIRE((px || S == 0) && py, "%s: the plain family needs px and py", what);
     FTR_REQUIRE(p_grad, "%s: the plain family needs the p_grad scratch lattice", what);
     return mi_plain_bwd(px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
   }
+#endif
   return mi_bidir_bwd(boundary, p, p_floats, flags, px_grad, py_grad, ans_grad, overwrite_ans_grad, B, S, T, modified, st);
 }
 }  // namespace
@@ -657,6 +675,7 @@ int ftr_selftest(void* scratch_dev, void* stream) {
   return selftest(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<int*>(scratch_dev));
 }
 
+#ifdef FTR_DIAG
 int ftr_debug_stamps(unsigned long long* out16) {
   clear_error();
   FTR_REQUIRE(out16, "debug_stamps: null pointer");
@@ -672,5 +691,6 @@ int ftr_debug_trace(unsigned long long* out, int n) {
   if (rc != FTR_OK) return rc;
   return debug_trace(out, n);
 }
+#endif
 
 }  // extern "C"

@@ -1052,38 +1052,6 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
   const int frow = lane >> 2, fq = lane & 3;
   f4 rg[NPF][4];
 
-  auto load_general = [&](int k, f4 (&gq)[4]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = 16 * m + frow;
-      const int r = row0 + row;
-      const int c0 = CH * k + 4 * fq - SKEW * row;
-      f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (r < Sn) {
-        if (REVM) {
-          // element e is walk column c0+e, i.e. t = te - c0 - e; memory order is the reverse of e.
-          const ptrdiff_t lo = (ptrdiff_t)(bd.se - r) * (T + 1) + bd.te - c0 - 3;
-          if (c0 >= 0 && c0 + 3 < Tn) {
-            v = *reinterpret_cast<const f4u*>(wsb + lo);          // memory order; park() reverses
-          } else if (c0 + 3 >= 0 && c0 < Tn) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c0 + e >= 0 && c0 + e < Tn) v[3 - e] = wsb[lo + 3 - e];
-          }
-        } else {
-          const ptrdiff_t o = (ptrdiff_t)(bd.sb + r) * (T + 1) + bd.tb + c0;
-          if (c0 >= 0 && c0 + 3 < Tn) {
-            v = *reinterpret_cast<const f4u*>(wsb + o);
-          } else if (c0 + 3 >= 0 && c0 < Tn) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c0 + e >= 0 && c0 + e < Tn) v[e] = wsb[o + e];
-          }
-        }
-      }
-      gq[m] = v;
-    }
-  };
   auto park = [&](int kk, const f4 (&gq)[4], auto edge_tag) {
     constexpr bool edge = decltype(edge_tag)::value;
     f4* dG = FTR_TG(kk);

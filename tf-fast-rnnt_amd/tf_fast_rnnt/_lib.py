@@ -25,8 +25,6 @@ _SIGNATURES = {
     "ftr_abi_version": (ctypes.c_int, []),
     "ftr_package_version": (ctypes.c_char_p, []),
     "ftr_last_error": (ctypes.c_char_p, []),
-    "ftr_set_mi_impl": (ctypes.c_int, [_i]),
-    "ftr_get_mi_impl": (ctypes.c_int, []),
     "ftr_mutual_information_workspace_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "ftr_mutual_information_handoff_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "ftr_mutual_information_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
@@ -77,8 +75,6 @@ _SIGNATURES = {
     "ftr_simple_logprobs_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_bwd_lm_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _i, _c_fp, _i, _i, _i, _c_st]),
     "ftr_selftest": (_i, [ctypes.c_void_p, _c_st]),
-    "ftr_debug_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong)]),
-    "ftr_debug_trace": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 FTR_MI_WS_CLEAN = 1   # include/ftr.h

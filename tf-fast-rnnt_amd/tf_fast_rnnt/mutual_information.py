@@ -153,16 +153,14 @@ def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[t
         py_grad = torch.empty_like(py)
         # ans_grad := 1 like the op (tf_fast_rnnt_op.cc:104-107); the kernel overwrites it with
         # p_grad[s_begin,t_begin] as the reference's self-check does (overwrite_ans_grad = true, :109-110)
-        if ans_grad_is_one and L.ftr_get_mi_impl() == 0:
+        if ans_grad_is_one:
             ag, overwrite = None, 0          # NULL ans_grad = ones, no self-check write-back: one launch less
         else:
             ag = torch.ones((B,), dtype=torch.float32, device=px.device) if ans_grad is None else ans_grad.to(torch.float32).contiguous().clone()
             overwrite = 1
-        p_grad = None
-        if L.ftr_get_mi_impl() == 1:   # the plain family follows the reference and materialises p_grad
-            p_grad = torch.empty(B * (S + 1) * (T + 1), dtype=torch.float32, device=px.device)
+        # p_grad = NULL: the reference's [B,S+1,T+1] gradient lattice (tf_fast_rnnt_op.cc:90-91) never exists here
         _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), ws_floats, flags,
-                                                       _ptr(p_grad), _ptr(px_grad), _ptr(py_grad), _ptr(ag), overwrite,
+                                                       None, _ptr(px_grad), _ptr(py_grad), _ptr(ag), overwrite,
                                                        B, S, T, modified, st)
     return (ans, px_grad, py_grad, ag) if return_ans_grad_check else (ans, px_grad, py_grad)
 

@@ -481,7 +481,7 @@ def get_rnnt_prune_ranges(
 
 class _DoPruning(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, am, lm, ranges):
+    def forward(ctx, am, lm, ranges, dense):
         B, T, r = ranges.shape
         S1, C = lm.shape[1], lm.shape[2]
         am_c = am.detach().contiguous(); lm_c = lm.detach().contiguous()
@@ -489,10 +489,12 @@ class _DoPruning(torch.autograd.Function):
         # materialises it; here it stays a stride-0 view (as k2's fast_rnnt returns it), which a joiner's `am_pruned +
         # lm_pruned` consumes by broadcasting: B*T*r*C*4 bytes less to write here and to read there.  Values, shape and the
         # gradient (the sum over r, in the fused backward below) are the reference's; .contiguous() gives the dense tensor.
-        am_p = am_c.unsqueeze(2).expand(B, T, r, C)
+        # dense=True materialises it (one more [B,T,r,C] stream written by the same kernel): for callers that write into
+        # am_pruned, reshape it with .view(), or hand it to code that wants contiguous memory.
+        am_p = torch.empty((B, T, r, C), dtype=am.dtype, device=am.device) if dense else am_c.unsqueeze(2).expand(B, T, r, C)
         lm_p = torch.empty((B, T, r, C), dtype=lm.dtype, device=lm.device)
         with torch.cuda.device(am.device):
-            _lib.call("ftr_do_pruning_f32", _ptr(am_c), _ptr(lm_c), _ptr(ranges), None, _ptr(lm_p),
+            _lib.call("ftr_do_pruning_f32", _ptr(am_c), _ptr(lm_c), _ptr(ranges), _ptr(am_p) if dense else None, _ptr(lm_p),
                                                      B, T, S1, C, r, _stream_ptr(am))
         ctx.save_for_backward(ranges)
         ctx.lm_shape = tuple(lm.shape)
@@ -511,18 +513,25 @@ class _DoPruning(torch.autograd.Function):
         with torch.cuda.device(g_am_p.device):
             _lib.call("ftr_do_pruning_bwd_ws_f32", _ptr(g_am_p), _ptr(g_lm_p), _ptr(ranges), _ptr(g_am), _ptr(g_lm),
                       B, T, S1, C, r, _ptr(ws), ws_bytes, _stream_ptr(g_am_p))
-        return g_am, g_lm, None
+        return g_am, g_lm, None, None
 
 
-def do_rnnt_pruning(am: torch.Tensor, lm: torch.Tensor, ranges: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """rnnt_loss.py:763-812.  am [B,T,C], lm [B,S+1,C], ranges [B,T,s_range] -> two [B,T,s_range,C]."""
+def do_rnnt_pruning(am: torch.Tensor, lm: torch.Tensor, ranges: torch.Tensor, dense: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rnnt_loss.py:763-812.  am [B,T,C], lm [B,S+1,C], ranges [B,T,s_range] -> two [B,T,s_range,C].
+
+    ``am_pruned[b,t,k,:] = am[b,t,:]`` is a broadcast (rnnt_loss.py:803).  By default it is returned as a stride-0 VIEW of
+    ``am`` (as k2's fast_rnnt returns it): same values, shape and gradient as the reference's dense tensor, and a joiner's
+    ``am_pruned + lm_pruned`` reads it by broadcasting -- but it aliases ``am`` (changing ``am`` afterwards changes it),
+    it cannot be written in place and ``.view(-1, C)`` refuses it.  ``dense=True`` (an extension, not in the reference's
+    signature) returns the reference's materialised tensor, written by the same gather kernel; ``.contiguous()`` on the
+    view gives the same thing."""
     _require_gpu(am, "am"); _require_gpu(lm, "lm"); _require_gpu(ranges, "ranges")
     if am.dtype != torch.float32 or lm.dtype != torch.float32:
         raise TypeError("am and lm must be float32")
     if ranges.shape[0] != am.shape[0] or ranges.shape[0] != lm.shape[0] or am.shape[1] != ranges.shape[1]:
         raise ValueError("do_rnnt_pruning: inconsistent shapes")
     ranges = ranges.to(torch.int32).contiguous()
-    return _DoPruning.apply(am, lm, ranges)
+    return _DoPruning.apply(am, lm, ranges, bool(dense))
 
 
 class _PrunedLogprobs(torch.autograd.Function):
@@ -781,8 +790,12 @@ def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, l
         ratio_sum = _colsum_weighted(lm_probs, inv, B * (S + 1), C, st)                                 # [C]
         count = float(B * (S + 1))
         if process_group is not None:
-            torch.distributed.all_reduce(ratio_sum, group=process_group)
-            count *= torch.distributed.get_world_size(process_group)
+            # the mean runs over the rows of EVERY shard (rnnt_loss.py:1279-1280 on the global batch), and shards may hold
+            # different numbers of rows (uneven batch split, every rank padded to its own S): the local row count travels
+            # in the same all-reduce as the [C] sums and the reduced count -- a device scalar, no host read -- divides them
+            packed = torch.cat((ratio_sum, torch.full((1,), count, dtype=torch.float32, device=dev)))
+            torch.distributed.all_reduce(packed, group=process_group)
+            ratio_sum, count = packed[:C], packed[C]
         u = (ratio_sum / count + _TINY).contiguous()                                                    # :1279-1280
         # am_probs, am_max and am_probs . u in one pass over am (:1265-1268, :1281-1286)
         am_dot = torch.empty((B * T,), dtype=torch.float32, device=dev)
