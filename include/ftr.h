@@ -324,7 +324,9 @@ int ftr_smoothed_logprobs_fused_fwd_f32(const float* am, const float* lm, const 
 /* Backward towards am with the W^T . lm_probs contraction inside the kernel (f32 MFMA): replaces one of the two backward
  * matmuls AND ftr_*_logprobs_bwd_am_*: W is formed from g_px, g_py and prod while staging, the scatter by symbol runs as a
  * second small MFMA contraction against a one-hot operand, `damp` [B,T,C] never exists.  Scale arguments as in the _scaled
- * forms above.  Requires C % 4 == 0 (ftr_simple_logprobs_fused_supported). */
+ * forms above.  Requires ftr_simple_logprobs_fused_bwd_supported(T, C) != 0 (T % 4 == 0 and C % 4 == 0); other sizes take
+ * the library-GEMM route. */
+int ftr_simple_logprobs_fused_bwd_supported(int T, int C);
 int ftr_simple_logprobs_fused_bwd_am_f32(const float* gpx, const float* gpy, const float* scale, int scale_stride,
                                          float scale_mul, const float* prod, const float* lm_probs, const float* am_probs,
                                          const int32_t* symbols, const int32_t* boundary, int termination_symbol,

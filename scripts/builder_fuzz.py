@@ -38,7 +38,7 @@ def main(n=60, seed=0, tol=1e-4):
                 out += [loss.detach().cpu().numpy()] + [np.zeros(x.shape, np.float32) if x.grad is None else x.grad.cpu().numpy() for x in (a, l)]
             return out
 
-        os.environ["FTR_BUILDER_GEMM"] = "library"; os.environ.pop("FTR_BUILDER_BWD", None)
+        os.environ["FTR_BUILDER_GEMM"] = "library"; os.environ["FTR_BUILDER_BWD"] = "library"
         ref = run()
         os.environ["FTR_BUILDER_GEMM"] = "fused"; os.environ["FTR_BUILDER_BWD"] = "fused"
         got = run()

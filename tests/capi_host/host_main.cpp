@@ -7,6 +7,16 @@
 //   capi_host.bin <dir> B S T modified s_range cummin_rows cummin_cols
 //   in : <dir>/px.bin py.bin boundary.bin gx.bin gy.bin cummin_in.bin      out: ans.bin px_grad.bin py_grad.bin
 //                                                                               ans_grad.bin cummin_out.bin ranges.bin
+//
+// Second mode, the entry points that replace the reference's Python-level functions (what a TF binding would register as
+// additional ops), also from this compiled host:
+//   capi_host.bin pipeline <dir> B S T C r blank delay_penalty
+//   in : <dir>/am.bin lm.bin symbols.bin boundary.bin ranges.bin logits.bin
+//   out: builder_px.bin builder_py.bin         ftr_rowmax_exp_f32 x2 -> ftr_simple_logprobs_fused_fwd_f32  (when C % 4 == 0)
+//        am_pruned.bin lm_pruned.bin           ftr_do_pruning_f32 with both output pointers (what tf.broadcast_to + tf.gather give)
+//        lm_pruned_only.bin                    ftr_do_pruning_f32 with am_pruned = NULL (the gather alone)
+//        pruned_ans.bin logits_grad.bin        ftr_pruned_band_fwd_f32 -> ftr_mutual_information_band_ws_f32 ->
+//                                              ftr_pruned_band_bwd_scaled_f32 (reduction "mean": scale_mul = -1/B)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -44,7 +54,64 @@ static T* to_device(const std::vector<T>& v) {
 template <typename T>
 static T* device_alloc(size_t n) { T* d = nullptr; HIP_OK(hipMalloc(&d, (n ? n : 1) * sizeof(T))); return d; }
 
+static int pipeline_main(int argc, char** argv) {
+  if (argc != 10) { fprintf(stderr, "usage: %s pipeline dir B S T C r blank delay_penalty\n", argv[0]); return 1; }
+  const std::string dir = argv[2];
+  const int B = atoi(argv[3]), S = atoi(argv[4]), T = atoi(argv[5]), C = atoi(argv[6]), r = atoi(argv[7]), blank = atoi(argv[8]);
+  const double penalty = atof(argv[9]);
+  hipStream_t st;
+  HIP_OK(hipStreamCreate(&st));
+  const size_t nam = (size_t)B * T * C, nlm = (size_t)B * (S + 1) * C, nband = (size_t)B * T * r, nlog = nband * C;
+  float* am = to_device(read_file<float>(dir + "/am.bin", nam));
+  float* lm = to_device(read_file<float>(dir + "/lm.bin", nlm));
+  int32_t* sym = to_device(read_file<int32_t>(dir + "/symbols.bin", (size_t)B * S));
+  int32_t* bd = to_device(read_file<int32_t>(dir + "/boundary.bin", (size_t)B * 4));
+  int32_t* ranges = to_device(read_file<int32_t>(dir + "/ranges.bin", nband));
+  float* logits = to_device(read_file<float>(dir + "/logits.bin", nlog));
+
+  // get_rnnt_logprobs (rnnt_loss.py:63-223): row maxima + exponentials, then the fused normaliser contraction + px / py writer
+  int builder = 0;
+  if (ftr_simple_logprobs_fused_supported(C)) {
+    float* am_probs = device_alloc<float>(nam); float* lm_probs = device_alloc<float>(nlm);
+    float* am_max = device_alloc<float>((size_t)B * T); float* lm_max = device_alloc<float>((size_t)B * (S + 1));
+    const size_t npx = (size_t)B * S * (T + 1), npy = (size_t)B * (S + 1) * T;
+    float* px = device_alloc<float>(npx); float* py = device_alloc<float>(npy); float* prod = device_alloc<float>(npy);
+    FTR_CALL(ftr_rowmax_exp_f32(am, am_probs, am_max, (long long)B * T, C, st));
+    FTR_CALL(ftr_rowmax_exp_f32(lm, lm_probs, lm_max, (long long)B * (S + 1), C, st));
+    FTR_CALL(ftr_simple_logprobs_fused_fwd_f32(am, lm, sym, am_probs, lm_probs, am_max, lm_max, bd, blank, 0.0, px, py, prod, B, T, S, C, 0, st));
+    HIP_OK(hipStreamSynchronize(st));
+    write_file(dir + "/builder_px.bin", px, npx);
+    write_file(dir + "/builder_py.bin", py, npy);
+    builder = 1;
+  }
+
+  // do_rnnt_pruning (rnnt_loss.py:763-812): both outputs, then the gather alone
+  float* am_p = device_alloc<float>(nlog); float* lm_p = device_alloc<float>(nlog); float* lm_p2 = device_alloc<float>(nlog);
+  FTR_CALL(ftr_do_pruning_f32(am, lm, ranges, am_p, lm_p, B, T, S + 1, C, r, st));
+  FTR_CALL(ftr_do_pruning_f32(am, lm, ranges, nullptr, lm_p2, B, T, S + 1, C, r, st));
+
+  // rnnt_loss_pruned on the band (rnnt_loss.py:1022-1130): builder, recursion forward + backward, gradient w.r.t. logits
+  if (ftr_mutual_information_band_supported(T, S, r) == 0) { fprintf(stderr, "band kernels do not cover T=%d S=%d r=%d\n", T, S, r); return 9; }
+  float* lse = device_alloc<float>(nband); float* pxb = device_alloc<float>(nband); float* pyb = device_alloc<float>(nband);
+  float* gxb = device_alloc<float>(nband); float* gyb = device_alloc<float>(nband); float* ans = device_alloc<float>(B);
+  float* glog = device_alloc<float>(nlog);
+  const size_t nws = ftr_mutual_information_band_workspace_floats(B, T, S, r);
+  float* ws = device_alloc<float>(nws);
+  FTR_CALL(ftr_pruned_band_fwd_f32(logits, sym, ranges, bd, blank, penalty, lse, pxb, pyb, B, T, S, C, r, 0, st));
+  FTR_CALL(ftr_mutual_information_band_ws_f32(pxb, pyb, ranges, bd, nws ? ws : nullptr, nws, ans, gxb, gyb, B, T, S, r, 0, st));
+  FTR_CALL(ftr_pruned_band_bwd_scaled_f32(logits, sym, ranges, bd, blank, lse, gxb, gyb, nullptr, 0, -1.0f / (float)B, glog, B, T, S, C, r, 0, st));
+  HIP_OK(hipStreamSynchronize(st));
+  write_file(dir + "/am_pruned.bin", am_p, nlog);
+  write_file(dir + "/lm_pruned.bin", lm_p, nlog);
+  write_file(dir + "/lm_pruned_only.bin", lm_p2, nlog);
+  write_file(dir + "/pruned_ans.bin", ans, (size_t)B);
+  write_file(dir + "/logits_grad.bin", glog, nlog);
+  printf("capi_host pipeline OK: B=%d S=%d T=%d C=%d r=%d builder=%d band workspace %zu floats\n", B, S, T, C, r, builder, nws);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && std::string(argv[1]) == "pipeline") return pipeline_main(argc, argv);
   if (argc != 9) { fprintf(stderr, "usage: %s dir B S T modified s_range cummin_rows cummin_cols\n", argv[0]); return 1; }
   const std::string dir = argv[1];
   const int B = atoi(argv[2]), S = atoi(argv[3]), T = atoi(argv[4]), modified = atoi(argv[5]), s_range = atoi(argv[6]);

@@ -677,10 +677,11 @@ def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cf
 
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
-@pytest.mark.parametrize("cfg", [(2, 70, 33, 12), (2, 129, 100, 20), (1, 200, 140, 260), (2, 65, 200, 8), (3, 64, 15, 36)])
+@pytest.mark.parametrize("cfg", [(2, 72, 33, 12), (2, 129, 100, 20), (1, 200, 140, 260), (2, 68, 200, 8), (3, 64, 15, 36), (2, 100, 7, 600), (1, 76, 330, 16),
+                                 (2, 132, 61, 1024), (2, 4, 3, 4), (1, 60, 0, 8)])
 def test_fused_d_am_kernel_matches_library_gemm_route(ft, dev, rnnt_type, cfg, monkeypatch):
-    """The opt-in fused backward towards am (FTR_BUILDER_BWD=fused: W^T lm_probs as MFMA inside the kernel, scatter by
-    symbol as a one-hot MFMA contraction) against the default route (library GEMM + epilogue kernel): gradients of the
+    """The fused backward towards am (the default: W^T lm_probs as MFMA inside the kernel, scatter by symbol as a one-hot
+    MFMA contraction) against the library route (FTR_BUILDER_BWD=library: library GEMM + epilogue kernel): gradients of the
     simple and of the smoothed loss w.r.t. am and lm, with boundaries and a non-uniform upstream gradient."""
     B, T, S, C = cfg
     d = synthetic(23 + S, B, T, S, C, ragged=True)
@@ -700,6 +701,7 @@ def test_fused_d_am_kernel_matches_library_gemm_route(ft, dev, rnnt_type, cfg, m
             out += [am.grad.cpu().numpy(), lm.grad.cpu().numpy()]
         return out
 
+    monkeypatch.setenv("FTR_BUILDER_BWD", "library")
     library = grads()
     monkeypatch.setenv("FTR_BUILDER_BWD", "fused")
     fused = grads()

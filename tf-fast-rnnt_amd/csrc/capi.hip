@@ -507,6 +507,7 @@ int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const in
 }
 
 int ftr_simple_logprobs_fused_supported(int C) { return simple_fused_supported(C); }
+int ftr_simple_logprobs_fused_bwd_supported(int T, int C) { return simple_fused_bwd_supported(T, C); }
 
 int ftr_simple_logprobs_fused_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
                                       const float* lm_probs, const float* am_max, const float* lm_max,
@@ -614,8 +615,9 @@ int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const i
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  rc = lse_rows(logits, lse, (size_t)B * T * r, C, st);
-  if (rc != FTR_OK) return rc;
+  bool gathered = false;   // one pass where the row fits the wave's registers (C % 4 == 0, C <= 1024), else lse + gather kernels
+  rc = lse_rows_band(logits, symbols, ranges, boundary, termination_symbol, delay_penalty, lse, px_band, py_band, B, T, S, C, r, modified, &gathered, st);
+  if (rc != FTR_OK || gathered) return rc;
   return band_gather(logits, symbols, ranges, boundary, lse, termination_symbol, delay_penalty, px_band, py_band, B, T, S, C, r, modified, st);
 }
 

@@ -141,10 +141,12 @@ int simple_logprobs_bwd_w(const float* gpx, const float* gpy, Scale scale, const
 int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* damp, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
 int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx, const float* rsy, int blank, float kdir, const float* arow, const float* invsum, const float* gu, float* d_lm, int B, int S, int C, hipStream_t st);
 int simple_fused_supported(int C);
+int simple_fused_bwd_supported(int T, int C);
 int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, const float* am_probs, const float* lm_probs, const float* am_max, const float* lm_max, const int32_t* boundary, int blank, double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog, float cs, float ls, float as, float* px, float* py, float* prod_out, int B, int T, int S, int C, int modified, hipStream_t st);
 int simple_fused_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* prod, const float* lm_probs, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float cs, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
 int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);
 int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st);
+int lse_rows_band(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, bool* gathered, hipStream_t st);
 int mi_band_supported(int T, int S, int r);
 int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st);
 int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, hipStream_t st);

@@ -104,11 +104,14 @@ __global__ void prune_argmax_kernel(const float* __restrict__ px_grad, const flo
   s_begin[(size_t)b * T + t] = (t < te - 1) ? best : pad;                // :741-748
 }
 
+#ifndef FTR_PRUNE_CHK
+#define FTR_PRUNE_CHK 64
+#endif
 // The same with the window length as a template parameter (1 <= R <= 16): every py_grad value is LOADED ONCE.  The lag
 // cumsum consumes, R rows later, what the lead cumsum loaded (carried in registers across chunks), in the same order
 // and with the same additions, so the sums -- and the ranges -- are bit-identical to the kernel above.
 template <int R>
-__global__ void prune_argmax_once_kernel(const float* __restrict__ px_grad, const float* __restrict__ py_grad,
+__global__ __launch_bounds__(64) void prune_argmax_once_kernel(const float* __restrict__ px_grad, const float* __restrict__ py_grad,
                                          const int32_t* __restrict__ boundary, int32_t* __restrict__ s_begin,
                                          int B, int S, int T, int T1) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,7 +121,7 @@ __global__ void prune_argmax_once_kernel(const float* __restrict__ px_grad, cons
   const int nwin = S1 - R + 1;
   const float* pyc = py_grad + (size_t)b * S1 * T + t;
   const float* pxc = px_grad + (size_t)b * S * T1 + t;
-  constexpr int CHK = 16;
+  constexpr int CHK = FTR_PRUNE_CHK;   // rows in flight per array and register set: the walk is sequential, so its time is (rows / CHK) memory round trips
   // v[i] of a chunk starting at window c0 is py_grad row c0 + i (i < CHK + R): rows c0 .. c0+R-1 come from the previous
   // chunk's tail (`carry`), rows c0+R .. c0+CHK+R-1 are loaded (the "lead" rows of this chunk's windows)
   float carry[R];

@@ -227,36 +227,59 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
 // d am[b,t,c] = am_probs[b,t,c] * sum_s W[b,s,t] lm_probs[b,s,c]  +  kdir * (sum_{s: sym(s) = c} gx[b,s,t] + [c = blank] sum_s gy[b,s,t])
 //               (+ smoothed: am_probs[b,t,c] * u[c] * R[b,t],  R = -as * colsum_s(gx + gy) / (am_probs . u))
 // with W = -cs (gx + gy) / (prod + tiny), gx = g_px masked where the forward wrote -inf, both times the upstream scale
-// (what TF autodiff replays for rnnt_loss.py:180-221 / :1296-1365 towards am).  Round 1 ran this as W kernel -> library GEMM
-// (damp [B,T,C] through memory) -> scatter/epilogue kernel.  Here one workgroup owns 64 frames x 16 NCB columns and loops
-// over the symbol rows twice with the SAME accumulators:
-//   pass 1  acc[c,t] += lm_probs[s,c] * W[s,t]          (MFMA; W formed from g_px, g_py, prod while staging)
+// (what TF autodiff replays for rnnt_loss.py:180-221 / :1296-1365 towards am).  The unfused route runs this as W kernel ->
+// library GEMM (damp [B,T,C] through memory) -> scatter / epilogue kernel.  Here a workgroup owns 64 frames x 256 columns
+// (two workgroups per CU, like the forward kernel: one's epilogue and loads overlap the other's MFMAs) and walks the symbol
+// rows twice with the SAME accumulators:
+//   pass 1  acc[c,t] += lm_probs[s,c] * W[s,t]          (MFMA; W formed from g_px, g_py, prod while the chunk is staged)
 //           acc = am_probs * (acc + u R)                (column sums for R and the blank term were taken while staging)
-//   pass 2  acc[c,t] += onehot(sym(s) = c) * kdir gx[s,t]   (the scatter by symbol as a second small MFMA contraction:
-//                                                        exact 0/1 products, no LDS scatter tile, no atomics)
-// MFMA roles: M = columns, N = frames, so a lane's accumulator quad is four consecutive columns of one frame: am_probs is
-// read and d am written 16 bytes per lane.  C % 4 == 0.
+//   pass 2  acc[c,t] += onehot(sym(s) = c) * kdir gx[s,t]   the scatter by symbol as a second small MFMA contraction (exact
+//                                                        0/1 products, deterministic, no scatter tile, no atomics)
+// Every load of the staging is UNCONDITIONAL: addresses are clamped into the arrays and what was loaded out of range is
+// multiplied away (a load under a condition costs an exec-masked branch each and makes the compiler wait for all of them;
+// the first versions of this kernel -- 16-byte loads under row / column / frame conditions, 512 columns per workgroup at one
+// workgroup per CU -- ran at a quarter of the matrix rate: 165 - 196 us at c3 against 63 + 61 for the tuned library GEMM
+// plus the epilogue kernel).  Needs T % 4 == 0 and C % 4 == 0 (other shapes take the library route).
+// MFMA roles: M = columns, N = frames.  Column blocks are INTERLEAVED: block i = 4 g + e holds the local columns
+// 64 g + 4 m + e (m = 0..15), so that ONE 16-byte LDS read -- columns 64 g + 4 fn .. + 3 of a k row -- is the A operand of the
+// four blocks of group g, and the accumulators of a group, acc[4g + 0..3][j], are four CONSECUTIVE columns
+// 64 g + 16 fk + 4 j + (0..3) of frame fn: am_probs is read and d am written 16 bytes at a time.
 constexpr int kBT = 64;                           // frames per workgroup
 constexpr int kBS = 16;                           // symbol rows per staged chunk (four MFMA k-steps)
+constexpr int kBLT = kBT + 4;                     // W tile row stride (floats)
+constexpr int kBCB = 16;                          // column blocks per workgroup (256 columns)
 
-template <int NCB>
 __host__ __device__ constexpr size_t fused_bwd_lds_bytes() {
-  return sizeof(float) * (2 * kBS * (16 * NCB + 4) + 2 * kBS * (kBT + 4) + 2 * kBS * kBT) + sizeof(int) * 2 * kBS;
+  return sizeof(float) * (2 * kBS * (16 * kBCB) + 2 * kBS * kBLT + 2 * kBS * kBT) + sizeof(int) * 2 * kBS;
 }
 
-template <bool MOD, int NCB>
+template <bool MOD>
 __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
     const float* __restrict__ gpx, const float* __restrict__ gpy, const Scale scale, const float* __restrict__ prod,
     const float* __restrict__ lm_probs, const float* __restrict__ am_probs, const int32_t* __restrict__ symbols,
     const int32_t* __restrict__ boundary, int blank, float cs, float kdir, const float* __restrict__ uvec,
     const float* __restrict__ amdot, float as, float* __restrict__ Rout, float* __restrict__ d_am, int T, int S, int C) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int CT = 16 * NCB, LDC = CT + 4, LDT = kBT + 4;
+  // lm tile rows are CT floats apart with no padding: a fragment read is 16 bytes per lane, 16 consecutive lanes = 256
+  // contiguous bytes of one k row, and rows a multiple of 256 bytes apart keep the four rows of a k-step on disjoint banks
+  constexpr int NCB = kBCB, CT = 16 * NCB, LDC = CT, NG = NCB / 4;
   float* lmT = smem;                               // [2][kBS][LDC]   lm_probs rows of the chunk
-  float* wT = lmT + 2 * kBS * LDC;                 // [2][kBS][LDT]   W (pass 1) / kdir * gx (pass 2) rows of the chunk
-  float* csb = wT + 2 * kBS * LDT;                 // [2][kBS][kBT]   partial column sums (x, y) per staging row class
+  float* wT = lmT + 2 * kBS * LDC;                 // [2][kBS][kBLT]  W (pass 1) / kdir * gx (pass 2) rows of the chunk
+  float* csb = wT + 2 * kBS * kBLT;                // [2][kBS][kBT]   partial column sums (x, y) per staging row class
   int* symL = reinterpret_cast<int*>(csb + 2 * kBS * kBT);   // [2][kBS]
-  const int b = blockIdx.z, t0 = blockIdx.x * kBT, c0 = blockIdx.y * CT;
+  // XCD-aware tile order (as in the forward kernel): workgroups are dealt to the eight XCDs round robin by linear id and
+  // every XCD has its own L2; in launch order the tiles that share one utterance's lm_probs rows and one frame tile's
+  // g_px / g_py / prod columns land on eight different L2s.  Here XCD k works through a contiguous eighth of the tile list.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7u) == 0) {
+      const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned j = (lin & 7u) * (total >> 3) + (lin >> 3);
+      by = j % gridDim.y; bx = (j / gridDim.y) % gridDim.x; bz = j / (gridDim.x * gridDim.y);   // column groups of a frame tile adjacent
+    }
+  }
+  const int b = bz, t0 = bx * kBT, c0 = by * CT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T1 = MOD ? T : T + 1;
@@ -268,49 +291,37 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
   const float* lmb = lm_probs + (size_t)b * (S + 1) * C;
   const int nk = (S + 1 + kBS - 1) / kBS;
 
-  // ---- staging plan.  lm tile: piece e = tid + 256 u (u < NL) = 4 columns of one of the chunk's rows.
-  constexpr int NL = (kBS * CT / 4 + 255) / 256;
-  // W / x tile: row tid / 16 of the chunk, frames t0 + 4 (tid % 16) .. +3
-  const int wrow = tid >> 4, wt = t0 + 4 * (tid & 15);
-  const bool wthread = tid < kBS * (kBT / 4);
-  auto load_lm = [&](int kc, f4 (&v)[NL]) {
+  // ---- staging plan.  lm tile: piece e = tid + 256 u (u < NL) = 4 columns of one of the chunk's rows (column clamped).
+  constexpr int NL = (kBS * CT / 4) / 256;         // 4
+  int lrow[NL], lcol[NL];
+  float lmask[NL];
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int e = tid + 256 * u, row = e / (CT / 4), c = c0 + 4 * (e % (CT / 4));
-      const int s = kc * kBS + row;
-      v[u] = f4{0.f, 0.f, 0.f, 0.f};
-      if (e < kBS * CT / 4 && s <= S && c < C) v[u] = *reinterpret_cast<const f4*>(lmb + (size_t)s * C + c);
-    }
-  };
-  auto store_lm = [&](int buf, const f4 (&v)[NL]) {
+  for (int u = 0; u < NL; ++u) {
+    const int e = tid + 256 * u, c = c0 + 4 * (e % (CT / 4));
+    lrow[u] = e / (CT / 4);
+    lcol[u] = min(c, C - 4);
+    lmask[u] = c < C ? 1.0f : 0.0f;
+  }
+  // W / x tile: row tid / 16 of the chunk, frames t0 + 4 (tid % 16) .. +3 (T % 4 == 0: a quad is inside [0, T) or outside)
+  const int wrow = tid >> 4, wq = tid & 15, wt = t0 + 4 * wq;
+  const int wtc = min(wt, T - 4);
+  const float tmask = wt < T ? 1.0f : 0.0f;
+  f4 xmask;                                        // g_px counts where the forward wrote a finite px: every frame but t_end (regular)
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int e = tid + 256 * u, row = e / (CT / 4), c4 = e % (CT / 4);
-      if (e < kBS * CT / 4) *reinterpret_cast<f4*>(lmT + (buf * kBS + row) * LDC + 4 * c4) = v[u];
-    }
-  };
-  // masked, scaled gradients of the chunk row this thread stages: x = g_px (0 where the forward wrote -inf), y = g_py
-  auto load_xy = [&](int kc, f4& x, f4& y, f4& pr, bool want_pr) {
+  for (int e = 0; e < 4; ++e) xmask[e] = (wt < T && (MOD || wt + e != te)) ? sc : 0.0f;
+  struct Stage { f4 lv[NL]; f4 x, y, pr; };
+  auto load = [&](int kc, Stage& g, bool want_all) {
     const int s = kc * kBS + wrow;
-    x = f4{0.f, 0.f, 0.f, 0.f}; y = x; pr = f4{1.f, 1.f, 1.f, 1.f};
-    if (!wthread || s > S || wt >= T) return;
-    if (wt + 3 < T) {
-      if (s < S) x = *reinterpret_cast<const f4u*>(gxb + (size_t)s * T1 + wt);
-      y = *reinterpret_cast<const f4u*>(gyb + (size_t)s * T + wt);
-      if (want_pr) pr = *reinterpret_cast<const f4u*>(prb + (size_t)s * T + wt);
-    } else {
-      for (int e = 0; e < 4; ++e) if (wt + e < T) {
-        if (s < S) x[e] = gxb[(size_t)s * T1 + wt + e];
-        y[e] = gyb[(size_t)s * T + wt + e];
-        if (want_pr) pr[e] = prb[(size_t)s * T + wt + e];
-      }
-    }
+    const int sy_ = min(s, S), sx_ = min(s, S > 0 ? S - 1 : 0);
+    if (want_all) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      x[e] *= sc; y[e] *= sc;
-      if (!MOD && wt + e == te) x[e] = 0.0f;
+      for (int u = 0; u < NL; ++u) g.lv[u] = *reinterpret_cast<const f4*>(lmb + (size_t)min(kc * kBS + lrow[u], S) * C + lcol[u]);
+      g.y = *reinterpret_cast<const f4u*>(gyb + (size_t)sy_ * T + wtc);
+      g.pr = *reinterpret_cast<const f4u*>(prb + (size_t)sy_ * T + wtc);
     }
+    g.x = (S > 0) ? (f4)*reinterpret_cast<const f4u*>(gxb + (size_t)sx_ * T1 + wtc) : f4{0.f, 0.f, 0.f, 0.f};
   };
+  f4 sx = {0.f, 0.f, 0.f, 0.f}, sy = {0.f, 0.f, 0.f, 0.f};   // column sums of this thread's row class
 
   v4f acc[NCB];
 #pragma unroll
@@ -318,39 +329,63 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
   const int fk = lane >> 4, fn = lane & 15;        // MFMA fragment coordinates of this lane: k row, m / n index
 
   // =================================================================== pass 1: acc[c,t] += lm_probs[s,c] W[s,t]
-  f4 sx = {0.f, 0.f, 0.f, 0.f}, sy = {0.f, 0.f, 0.f, 0.f};   // column sums of this thread's row class
   {
-    f4 lv[NL], x, y, pr;
-    load_lm(0, lv); load_xy(0, x, y, pr, true);
-    auto store_w = [&](int buf) {
-      if (!wthread) return;
+    auto park = [&](int kc, const Stage& g) {
+      const int buf = kc & 1;
+#pragma unroll
+      for (int u = 0; u < NL; ++u) {
+        const float m = (kc * kBS + lrow[u] <= S) ? lmask[u] : 0.0f;
+        *reinterpret_cast<f4*>(lmT + (buf * kBS + lrow[u]) * LDC + 4 * ((tid + 256 * u) % (CT / 4))) = g.lv[u] * m;
+      }
+      const int s = kc * kBS + wrow;
+      const float rowy = s <= S ? sc * tmask : 0.0f, rowx = s < S ? 1.0f : 0.0f;
+      const f4 x = g.x * xmask * rowx, y = g.y * rowy;
       f4 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { w[e] = -cs * (x[e] + y[e]) / (pr[e] + kTinyF); }
+      for (int e = 0; e < 4; ++e) w[e] = -cs * (x[e] + y[e]) / (g.pr[e] + kTinyF);
       sx += x; sy += y;
-      *reinterpret_cast<f4*>(wT + (buf * kBS + wrow) * LDT + 4 * (tid & 15)) = w;
+      *reinterpret_cast<f4*>(wT + (buf * kBS + wrow) * kBLT + 4 * wq) = w;
     };
-    store_lm(0, lv); store_w(0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
+    auto compute = [&](int kc) {
       const int buf = kc & 1;
-      if (kc + 1 < nk) { load_lm(kc + 1, lv); load_xy(kc + 1, x, y, pr, true); }
+      const float* abase = lmT + (buf * kBS + fk) * LDC + 4 * fn;
+      const float* bbase = wT + (buf * kBS + fk) * kBLT + 16 * wave + fn;
+      f4 af[2][NG];
+      float bw[kBS / 4];
+#pragma unroll
+      for (int kk = 0; kk < kBS / 4; ++kk) bw[kk] = bbase[4 * kk * kBLT];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) af[0][g] = *reinterpret_cast<const f4*>(abase + 64 * g);
 #pragma unroll
       for (int kk = 0; kk < kBS / 4; ++kk) {
-        const float bw = wT[(buf * kBS + 4 * kk + fk) * LDT + 16 * wave + fn];
-        const float* arow = lmT + (buf * kBS + 4 * kk + fk) * LDC + fn;
+        if (kk + 1 < kBS / 4) {
 #pragma unroll
-        for (int i = 0; i < NCB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * i], bw, acc[i], 0, 0, 0);
+          for (int g = 0; g < NG; ++g) af[(kk + 1) & 1][g] = *reinterpret_cast<const f4*>(abase + 4 * (kk + 1) * LDC + 64 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the next k-step's fragments are requested BEFORE this k-step's MFMAs: left alone
+                                             // the scheduler sinks every read to its first use and waits for it there
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][g][e], bw[kk], acc[4 * g + e], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (kc + 1 < nk) { store_lm(buf ^ 1, lv); store_w(buf ^ 1); }
+    };
+    Stage g;
+    load(0, g, true);
+    park(0, g);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk) load(kc + 1, g, true);
+      compute(kc);
+      if (kc + 1 < nk) park(kc + 1, g);
       __syncthreads();
     }
   }
   // ---- column sums over s of x and y for this lane's frame (blank term, R), then acc = am_probs * (acc + u R)
-  if (wthread) {
-    *reinterpret_cast<f4*>(csb + (0 * kBS + wrow) * kBT + 4 * (tid & 15)) = sx;
-    *reinterpret_cast<f4*>(csb + (1 * kBS + wrow) * kBT + 4 * (tid & 15)) = sy;
-  }
+  *reinterpret_cast<f4*>(csb + (0 * kBS + wrow) * kBT + 4 * wq) = sx;
+  *reinterpret_cast<f4*>(csb + (1 * kBS + wrow) * kBT + 4 * wq) = sy;
   __syncthreads();
   const int tl = 16 * wave + fn, t = t0 + tl;
   float cx = 0.0f, cy = 0.0f;
@@ -360,61 +395,70 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
   float R = 0.0f;
   if (uvec && tok) {
     R = -as * (cx + cy) / amdot[(size_t)b * T + t];
-    if (blockIdx.y == 0 && fk == 0) Rout[(size_t)b * T + t] = R;
+    if (by == 0 && fk == 0) Rout[(size_t)b * T + t] = R;
   }
   const float* aprow = am_probs + ((size_t)b * T + (tok ? t : 0)) * C;
 #pragma unroll
-  for (int i = 0; i < NCB; ++i) {
-    const int c = c0 + 16 * i + 4 * fk;
-    f4 ap = {0.f, 0.f, 0.f, 0.f};
-    if (tok && c < C) ap = *reinterpret_cast<const f4*>(aprow + c);
-    if (uvec) {
-      f4 uv = {0.f, 0.f, 0.f, 0.f};
-      if (c < C) uv = *reinterpret_cast<const f4*>(uvec + c);
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = ap[j] * (acc[i][j] + uv[j] * R);
-    } else {
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + 64 * g + 16 * fk + 4 * j;      // acc[4g + e][j] is column c + e
+      f4 ap = {0.f, 0.f, 0.f, 0.f};
+      if (tok && c < C) ap = *reinterpret_cast<const f4*>(aprow + c);
+      if (uvec) {
+        f4 uv = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) uv = *reinterpret_cast<const f4*>(uvec + c);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = ap[j] * acc[i][j];
+        for (int e = 0; e < 4; ++e) acc[4 * g + e][j] = ap[e] * (acc[4 * g + e][j] + uv[e] * R);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e][j] = ap[e] * acc[4 * g + e][j];
+      }
     }
-  }
   // =================================================================== pass 2: acc[c,t] += [sym(s) = c] kdir gx[s,t]
+  // Little arithmetic (at most four MFMAs per k-step), so the rows are staged 128 at a time into the idle lm tile area: two
+  // round trips to memory at S = 200 instead of thirteen (taken 16 rows at a time, as pass 1 is, this pass was a third of
+  // the kernel: every iteration waited for its loads with nothing to overlap them with).
   {
-    f4 x, y, pr;
-    int symr = -1;
-    auto load_sym = [&](int kc) {
-      symr = -1;
-      if (tid < kBS) { const int s = kc * kBS + tid; if (s < S) symr = min(max(symbols[(size_t)b * S + s], 0), C - 1); }
-    };
-    auto store_x = [&](int buf) {
-      if (wthread) *reinterpret_cast<f4*>(wT + (buf * kBS + wrow) * LDT + 4 * (tid & 15)) = x * kdir;
-      if (tid < kBS) symL[buf * kBS + tid] = symr;
-    };
-    const int nk2 = (S + kBS - 1) / kBS;            // rows s < S only
-    if (nk2 > 0) {
-      load_xy(0, x, y, pr, false); load_sym(0);
-      store_x(0);
+    constexpr int kB2 = 128;                       // rows per stage: kB2 * kBT floats = the lm tile area
+    static_assert(kB2 * kBT <= 2 * kBS * LDC && kB2 <= 2 * kBS * kBLT, "pass 2 reuses the tiles of pass 1");
+    float* xT = lmT;                               // [kB2][kBT]
+    int* sym2 = reinterpret_cast<int*>(wT);        // [kB2]
+    constexpr int NX = kB2 * (kBT / 4) / 256;      // 8 quads per thread and stage
+    for (int r0 = 0; r0 < S; r0 += kB2) {
+      f4 xv[NX];
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int row = r0 + wrow + 16 * u;
+        xv[u] = *reinterpret_cast<const f4u*>(gxb + (size_t)min(row, S - 1) * T1 + wtc);
+      }
+      const int srow = r0 + tid;
+      const int symr = (tid < kB2 && srow < S) ? min(max(symbols[(size_t)b * S + min(srow, S - 1)], 0), C - 1) : -1;
+      __syncthreads();                             // the previous stage (or pass 1 / the column sums) is done with the area
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const float rowx = (r0 + wrow + 16 * u < S) ? kdir : 0.0f;
+        *reinterpret_cast<f4*>(xT + (wrow + 16 * u) * kBT + 4 * wq) = xv[u] * xmask * rowx;
+      }
+      if (tid < kB2) sym2[tid] = symr;
       __syncthreads();
-      for (int kc = 0; kc < nk2; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk2) { load_xy(kc + 1, x, y, pr, false); load_sym(kc + 1); }
+      const int nks = (min(kB2, S - r0) + 3) / 4;
+      for (int kk = 0; kk < nks; ++kk) {
+        const float bx = xT[(4 * kk + fk) * kBT + 16 * wave + fn];
+        // this lane's A element (k row 4 kk + fk, block row fn) is 1 in block 4 g + e iff the row's symbol is local
+        // column 64 g + 4 fn + e
+        const int lc = sym2[4 * kk + fk] - c0;
+        const int myblk = (lc >= 0 && lc < CT && ((lc & 63) >> 2) == fn) ? 4 * (lc >> 6) + (lc & 3) : -1;
+        // only the (at most four) column blocks that a symbol of this k-step falls into do any work (wave-uniform mask)
+        unsigned mask = 0;
 #pragma unroll
-        for (int kk = 0; kk < kBS / 4; ++kk) {
-          const float bx = wT[(buf * kBS + 4 * kk + fk) * LDT + 16 * wave + fn];
-          const int rel = symL[buf * kBS + 4 * kk + fk] - c0 - fn;      // this lane's A element is 1 iff rel == 16 i
-          // only the (at most four) column blocks that a symbol of this k-step falls into do any work (wave-uniform mask)
-          unsigned mask = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int sb = __builtin_amdgcn_readfirstlane(symL[buf * kBS + 4 * kk + q]) - c0;
-            if (sb >= 0 && sb < CT) mask |= 1u << (sb >> 4);
-          }
-#pragma unroll
-          for (int i = 0; i < NCB; ++i)
-            if (mask & (1u << i)) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32((rel == 16 * i) ? 1.0f : 0.0f, bx, acc[i], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+          const int sb = __builtin_amdgcn_readfirstlane(sym2[4 * kk + q]) - c0;
+          if (sb >= 0 && sb < CT) mask |= 1u << (4 * (sb >> 6) + (sb & 3));
         }
-        if (kc + 1 < nk2) store_x(buf ^ 1);
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCB; ++i)
+          if (mask & (1u << i)) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32((myblk == i) ? 1.0f : 0.0f, bx, acc[i], 0, 0, 0);
       }
     }
   }
@@ -423,13 +467,15 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
   float* drow = d_am + ((size_t)b * T + t) * C;
   const float colb = kdir * cy;
 #pragma unroll
-  for (int i = 0; i < NCB; ++i) {
-    const int c = c0 + 16 * i + 4 * fk;
-    if (c >= C) continue;
-    f4 v = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-    if (blank >= c && blank < c + 4) v[blank - c] += colb;
-    *reinterpret_cast<f4*>(drow + c) = v;
-  }
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + 64 * g + 16 * fk + 4 * j;
+      if (c >= C) continue;
+      f4 v = {acc[4 * g + 0][j], acc[4 * g + 1][j], acc[4 * g + 2][j], acc[4 * g + 3][j]};
+      if (blank >= c && blank < c + 4) v[blank - c] += colb;
+      *reinterpret_cast<f4*>(drow + c) = v;
+    }
 }
 
 }  // namespace
@@ -476,22 +522,24 @@ int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, c
   return check_launch("simple_logprobs_fused_fwd");
 }
 
+// 0: outside the fused backward kernel's domain (needs C % 4 == 0, T % 4 == 0, C >= 4, T >= 4): the caller then takes
+// the library-GEMM route
+int simple_fused_bwd_supported(int T, int C) {
+  return (simple_fused_supported(C) && C >= 4 && T >= 4 && (T % 4) == 0) ? 1 : 0;
+}
+
 int simple_fused_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* prod, const float* lm_probs,
                         const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float cs,
                         float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B,
                         int T, int S, int C, int modified, hipStream_t st) {
-  if (!simple_fused_supported(C)) { set_error("simple_logprobs_fused_bwd_am: C = %d is not a multiple of 4", C); return FTR_ERR_UNSUPPORTED; }
-  const int blocks = (C + 15) / 16;
-  const int ncb = 16;                                          // column blocks per workgroup (24 / 32 run out of registers at two waves per SIMD)
-  const dim3 grid((T + kBT - 1) / kBT, (blocks + ncb - 1) / ncb, B);
+  if (!simple_fused_bwd_supported(T, C)) {
+    set_error("simple_logprobs_fused_bwd_am: T = %d, C = %d is outside the fused kernel's domain (T %% 4 == 0, C %% 4 == 0)", T, C);
+    return FTR_ERR_UNSUPPORTED;
+  }
+  const dim3 grid((T + kBT - 1) / kBT, (C + 16 * kBCB - 1) / (16 * kBCB), B);
   if (grid.z > 65535) { set_error("simple_logprobs_fused_bwd_am: B = %d > 65535", B); return FTR_ERR_UNSUPPORTED; }
-#define FTR_FBWD_LAUNCH(MODV, NCBV)                                                                                       \
-  hipLaunchKernelGGL((simple_fused_bwd_am_kernel<MODV, NCBV>), grid, dim3(256), fused_bwd_lds_bytes<NCBV>(), st, gpx, gpy, \
-                     scale, prod, lm_probs, am_probs, symbols, boundary, blank, cs, kdir, uvec, amdot, as, Rout, d_am, T, S, C)
-#define FTR_FBWD_NCB(MODV) FTR_FBWD_LAUNCH(MODV, 16)
-  if (modified) FTR_FBWD_NCB(true); else FTR_FBWD_NCB(false);
-#undef FTR_FBWD_NCB
-#undef FTR_FBWD_LAUNCH
+  if (modified) hipLaunchKernelGGL(simple_fused_bwd_am_kernel<true>, grid, dim3(256), fused_bwd_lds_bytes(), st, gpx, gpy, scale, prod, lm_probs, am_probs, symbols, boundary, blank, cs, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
+  else hipLaunchKernelGGL(simple_fused_bwd_am_kernel<false>, grid, dim3(256), fused_bwd_lds_bytes(), st, gpx, gpy, scale, prod, lm_probs, am_probs, symbols, boundary, blank, cs, kdir, uvec, amdot, as, Rout, d_am, T, S, C);
   return check_launch("simple_logprobs_fused_bwd_am");
 }
 

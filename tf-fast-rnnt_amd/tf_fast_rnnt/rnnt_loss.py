@@ -75,12 +75,16 @@ def _use_fused_builder(C: int) -> bool:
     return os.environ.get("FTR_BUILDER_GEMM", "fused") != "library" and bool(_lib.lib().ftr_simple_logprobs_fused_supported(int(C)))
 
 
-def _use_fused_builder_bwd(C: int) -> bool:
-    """The fused d am kernel (W^T lm_probs + scatter inside one kernel, csrc/simple_fused.hip) is opt-in
-    (FTR_BUILDER_BWD=fused): at B=32 T=1000 S=200 C=500 it takes 165 us against 63 + 61 us for the tuned library GEMM + the
-    epilogue kernel it replaces (short contraction, K = S+1: its operand staging is latency bound), so the library route
-    stays the default for the backward."""
-    return os.environ.get("FTR_BUILDER_BWD", "library") == "fused" and _use_fused_builder(C)
+def _use_fused_builder_bwd(T: int, C: int) -> bool:
+    """The fused d am kernel (W^T lm_probs + the scatter by symbol inside one kernel, csrc/simple_fused.hip: `damp` [B,T,C]
+    never goes through memory) where it is the faster route: measured on MI355X it beats library GEMM + epilogue kernel for
+    large vocabularies (B=32 T=2000 S=300 C=1024: 644 us against 308 + 405 with the tuned GEMM) and loses at C = 500 (141 us
+    against 63 + 62; 142 against the untuned GEMM), so the default ("auto") takes it from C >= 768.  FTR_BUILDER_BWD=fused /
+    library force a route (A/B comparisons and the route-vs-route tests)."""
+    mode = os.environ.get("FTR_BUILDER_BWD", "auto")
+    if mode == "library" or not _use_fused_builder(C) or not _lib.lib().ftr_simple_logprobs_fused_bwd_supported(int(T), int(C)):
+        return False
+    return mode == "fused" or C >= 768
 
 
 def _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, blank, delay_penalty, px, py,
@@ -146,7 +150,7 @@ class _SimpleLogprobs(torch.autograd.Function):
             _lib.call("ftr_simple_logprobs_bwd_w_f32", _ptr(gpx), _ptr(gpy), _ptr(prod), _ptr(boundary), _ptr(W),
                       _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
             dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-            if _use_fused_builder_bwd(C):                       # W^T lm_probs inside the d am kernel (opt-in)
+            if _use_fused_builder_bwd(T, C):                       # W^T lm_probs inside the d am kernel (opt-in)
                 _lib.call("ftr_simple_logprobs_fused_bwd_am_f32", _ptr(gpx), _ptr(gpy), None, 0, 1.0, _ptr(prod),
                           _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
                           modified, st)
@@ -217,7 +221,7 @@ class _SimpleLoss(torch.autograd.Function):
             _lib.call("ftr_simple_logprobs_bwd_w_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
                       _ptr(prod), _ptr(boundary), _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
             dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-            if _use_fused_builder_bwd(C):                       # W^T lm_probs inside the d am kernel (opt-in)
+            if _use_fused_builder_bwd(T, C):                       # W^T lm_probs inside the d am kernel (opt-in)
                 _lib.call("ftr_simple_logprobs_fused_bwd_am_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
                           _ptr(prod), _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am),
                           B, T, S, C, modified, st)
@@ -841,7 +845,7 @@ def _smoothed_backward(saved, has_boundary, meta, gpx, gpy, scale=None, stride=0
         _lib.call("ftr_smoothed_logprobs_bwd_w_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
                   _ptr(boundary), cs, _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
         dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
-        if _use_fused_builder_bwd(C):                       # W^T lm_probs inside the d am kernel (opt-in)
+        if _use_fused_builder_bwd(T, C):                       # W^T lm_probs inside the d am kernel (opt-in)
             _lib.call("ftr_smoothed_logprobs_fused_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
                       _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs, cs + a_s, _ptr(u),
                       _ptr(am_dot), a_s, _ptr(R), _ptr(d_am), B, T, S, C, modified, st)
