@@ -155,8 +155,8 @@ CALL_KERNELS = {
     "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
     "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_chunk_kernel<true>", "do_pruning_bwd_reduce_kernel"],
-    "ftr_pruned_logprobs_fwd_f32": ["lse_rows_kernel<true>", "band_to_lattice_kernel<false>"],
-    "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_gather_kernel<false>"],
+    "ftr_pruned_logprobs_fwd_f32": ["lse_rows_reg_kernel<2, 2, false>", "band_to_lattice_kernel<false>"],
+    "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2, true>"],     # lse + band gather in one pass (C % 4 == 0, C <= 1024)
     "ftr_mutual_information_band_f32": ["mi_band_kernel<false, 8>"],
     "ftr_mutual_information_band_ws_f32": ["mi_band_kernel<false, 8>"],
     "ftr_pruned_band_bwd_scaled_f32": ["band_grad_banded_kernel<true>"],
@@ -167,7 +167,7 @@ CALL_KERNELS = {
     "ftr_rowmax_exp_f32": ["rowmax_exp_kernel<true>"],
     "ftr_simple_logprobs_fwd_f32": ["simple_fwd_kernel<false, 16>"],
     "ftr_simple_logprobs_fused_fwd_f32": ["simple_fused_fwd_kernel<false, false, 13>"],
-    "ftr_simple_logprobs_fused_bwd_am_f32": ["simple_fused_bwd_am_kernel<false, 16>"],
+    "ftr_simple_logprobs_fused_bwd_am_f32": ["simple_fused_bwd_am_kernel<false>"],
     "ftr_simple_logprobs_bwd_w_f32": ["simple_bwd_w_kernel<false>"],
     "ftr_simple_logprobs_bwd_am_f32": ["simple_bwd_am_kernel<false>"],
     "ftr_simple_logprobs_bwd_lm_f32": ["simple_bwd_lm_kernel"],

@@ -208,7 +208,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
   // and with the static shift alone `ans` came out of the cancellation of two numbers of several thousand.  A uniform shift
   // of a whole anti-diagonal changes no split ratio.  frame(k) = step[0] + ... + step[k]; a stored value + frame(k) = the
   // (statically shifted) log-probability.  step[k + 3] is set by the IO-out wave from the largest value at the end of chunk
-  // k (it reads the compute wave's output tile anyway): step[k+3] = rint(max + 2.5 drift) - step[k+1] - step[k+2], three chunks ahead so
+  // k (the COMM wave reads the compute wave's output tile for it; it has slack in every slot): step[k+3] = rint(max + 2.5 drift) - step[k+1] - step[k+2], three chunks ahead so
   // that the COMM wave, which converts the values of the band above into this band's frame when it imports them (five
   // chunks before their use), already knows the frame they will be used in.  The steps travel to the band below in the tag
   // word of the granules, the frame of the cut values goes to the cut reduction (phimid).
@@ -337,25 +337,36 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     const bool has_up = w > 0;
     bool dead = false;
     u64 g_cur = 0;   // granule of chunk (kc + LOOK), loaded during the previous slot (tag 0 = not loaded)
-    // The shift constants of this utterance (ftr_common.h, Shift): a fixed sample of 512 elements of px and of py inside
-    // the rectangle, the same positions in every band and direction, so every workgroup of the utterance derives the same
-    // two numbers bit for bit.  This wave has nothing else to do in the warm-up slots: the 16 loads per lane go out now,
+    // The shift constants of this utterance (ftr_common.h, Shift): a fixed sample of 256 elements of px and of py inside
+    // the rectangle (four 64-column row segments each: eight cache lines per array, not one per element; the frames below
+    // take care of whatever drift a coarse mean leaves), the same positions in every band and direction, so every workgroup
+    // of the utterance derives the same two numbers bit for bit.  This wave has nothing else to do in the warm-up slots: the
+    // eight loads per lane go out now,
     // are reduced in slot kShiftSlot (the last warm-up slot: by then they have had three slots to arrive, and nothing queues
     // behind this wave's wait) and reach the IO-in wave through LDS one barrier later, at the top of the slot of its first park.
     constexpr int kShiftSlot = 3;
-    float smp_x[8], smp_y[8];
+    constexpr int kSeg = 4;   // segments per array: lane l reads column col0 + l of row `row` -- two cache lines per segment
+    float smp_x[kSeg], smp_y[kSeg];
     {
       const int nrx = Sn - 1, ncx = Tn - NOFF, nry = Sn, ncy = Tn - 1;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned i = (unsigned)(lane + 64 * u);
-        const unsigned hr = i * 0x9E3779B1u, hc = i * 0x85EBCA77u + 0x1234567u;
+      for (int u = 0; u < kSeg; ++u) {
+        const unsigned hr = (unsigned)(u + 1) * 0x9E3779B1u, hc = (unsigned)(u + 1) * 0x85EBCA77u + 0x1234567u;
         smp_x[u] = -INFINITY; smp_y[u] = -INFINITY;
-        if (nrx > 0 && ncx > 0) smp_x[u] = px[(ptrdiff_t)(bd.sb + (int)__umulhi(hr, (unsigned)nrx)) * T1 + bd.tb + (int)__umulhi(hc, (unsigned)ncx)];
-        if (ncy > 0) smp_y[u] = py[(ptrdiff_t)(bd.sb + (int)__umulhi(hr, (unsigned)nry)) * T + bd.tb + (int)__umulhi(hc, (unsigned)ncy)];
+        if (nrx > 0 && ncx > 0) {
+          const int c0 = (int)__umulhi(hc, (unsigned)max(ncx - 63, 1));
+          smp_x[u] = px[(ptrdiff_t)(bd.sb + (int)__umulhi(hr, (unsigned)nrx)) * T1 + bd.tb + min(c0 + lane, ncx - 1)];
+        }
+        if (ncy > 0) {
+          const int c0 = (int)__umulhi(hc, (unsigned)max(ncy - 63, 1));
+          smp_y[u] = py[(ptrdiff_t)(bd.sb + (int)__umulhi(hr, (unsigned)nry)) * T + bd.tb + min(c0 + lane, ncy - 1)];
+        }
       }
     }
     int frame_rel = 0;   // (frame of the band above at chunk m - 1) - (this band's frame at chunk kc)
+    int step_0 = 0, step_1 = 0, step_2 = 0;   // the steps scheduled for the next three chunks (see below)
+    float mx_prev = -INFINITY;                // the previous chunk's maximum (in that chunk's frame)
+    const bool lane_valid = 64 * w + lane < Sn;
     constexpr int kFirstUsed = MOD ? 0 : 3;   // first chunk of the band above whose values this band reads (regular: its step 63)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
@@ -363,7 +374,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       if (gg == kShiftSlot) {
         float sx = 0.0f, nx = 0.0f, sy = 0.0f, ny = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kSeg; ++u) {
           if (shift_sample_ok(smp_x[u])) { sx += smp_x[u]; nx += 1.0f; }
           if (shift_sample_ok(smp_y[u])) { sy += smp_y[u]; ny += 1.0f; }
         }
@@ -376,13 +387,38 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           if (w == 0 && !REVM) { pmid_store(cxy_b, sh.cx2); pmid_store(cxy_b + 1, sh.cy2); }   // for the cut reduction
         }
       }
+      // step[kc + 2] from the compute wave's values at the end of chunk kc - 1 (its output tile of the previous slot): where
+      // the largest value will be three chunks from now if it keeps drifting as it did during that chunk (drift = the change
+      // of the maximum plus the step that was taken out of it: absolute positions, so this is feed-forward, nothing
+      // oscillates), centred over that chunk, less the two steps that are already under way.  Done here, BEFORE the poll:
+      // this wave has slack in every slot (the IO-out wave, which did it first, has not), and the schedule must not wait
+      // for the band above.
+      {
+        const int k = kc - 1;
+        if (k >= 0 && k < klast) {
+          const float plast = reinterpret_cast<const float*>(FTR_TP(k))[((3 * PLANE + lane) << 2) + 3];
+          const float mx = wave_max_dpp((lane_valid && plast > kNegThresh) ? plast : -INFINITY);
+          int step_3 = 0;
+          if (mx > kNegThresh) {
+            const float drift = (mx_prev > kNegThresh) ? (mx - mx_prev) + (float)step_0 : 0.0f;
+            step_3 = min(max((int)__builtin_rintf(mx + 2.5f * drift) - step_1 - step_2, -kStepMax), kStepMax);
+          }
+#ifdef FTR_EXP_NOFRAMES   // study build: no renormalisation
+          step_3 = 0;
+#endif
+          mx_prev = mx;
+          if (lane == 0) sring[(k + 3) & 7] = (float)step_3;
+          step_0 = step_1; step_1 = step_2; step_2 = step_3;      // now: step_0 = step[k + 1], step_1 = step[k + 2], step_2 = step[k + 3]
+        }
+      }
 #ifdef FTR_EXP_NOPOLL
       if (false) {
 #else
       if (has_up && !dead && m >= 0 && m < klast_up) {
 #endif
-        // the values are for local chunk kc + 1: its step was written by the IO-out wave one slot ago
-        if (kc + 1 >= 0 && kc + 1 < klast) frame_rel -= (int)sring[(kc + 1) & 7];
+        // the values are for local chunk kc + 1, whose step this wave set one slot ago (step[kc + 1] = step_1 after the shift
+        // above; zero in the warm-up slots)
+        if (kc + 1 >= 0 && kc + 1 < klast) frame_rel -= step_1;
         if (!comm_wait(gran_in, m, lane, g_cur, status)) {   // producer never showed up: poison, stop polling
           dead = true;
           in_ring[lane] = __builtin_nanf("");
@@ -663,22 +699,18 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     auto clear_imported = [&](int mm) {   // what the COMM wave imported one slot ago: leave it zero for the next launch
       if (has_up && mm >= 0 && mm < klast_up) comm_clear(gran_in, mm, lane);
     };
-    // frame bookkeeping (see "Frames"): while chunk k is handled, frame_k = step[0] + ... + step[k], step_k = step[k],
-    // step_1 / step_2 = the steps already scheduled for chunks k + 1 / k + 2
-    int frame_k = 0, step_k = 0, step_1 = 0, step_2 = 0;
-    bool have_base = false;
-    float mx_prev = -INFINITY;   // the previous chunk's maximum (in that chunk's frame)
+    // frame bookkeeping (see "Frames"): while chunk k is handled, frame_k = base + step[0] + ... + step[k] (the steps are set
+    // by the COMM wave, three chunks ahead)
+    int frame_k = 0;
     const bool lane_valid = 64 * w + lane < Sn;
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int k = kc - 1;                 // the chunk the compute wave finished in the previous slot
       if (k >= 0 && k < klast) {
         const float* tp = reinterpret_cast<const float*>(FTR_TP(k));
-        const float plast = tp[((3 * PLANE + lane) << 2) + 3];   // this lane's value after the chunk's last step (for step[k + 3])
-        if (!have_base) {   // chunk 0: the base frame the COMM wave chose (slots ago) counts as chunk 0's step
-          have_base = true;
-          frame_k = step_k = (int)sring[8];
-        }
+        // chunk 0: the base frame the COMM wave chose (slots ago) counts as chunk 0's step
+        const int step_k = (int)sring[k & 7] + (k == 0 ? (int)sring[8] : 0);
+        frame_k += step_k;
 #ifdef FTR_EXP_NOPUBLISH   // test build (tests/test_gpu_mi.py poison path): the first alpha band never publishes
         if (has_down && lane < CH && !(w == 0 && !REVM)) {
 #else
@@ -693,21 +725,6 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           if (lane_valid) pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
           if (lane == 0) __hip_atomic_store(phimid_b + w, frame_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // step[k + 3]: where the largest value will be three chunks from now if it keeps drifting as it did during this
-        // chunk (drift = the change of the maximum plus the step that was taken out of it: absolute positions, so this is
-        // feed-forward, nothing oscillates), centred over that chunk, less the two steps that are already under way
-        const float mx = wave_max_dpp((lane_valid && plast > kNegThresh) ? plast : -INFINITY);
-        int step_3 = 0;
-        if (mx > kNegThresh) {
-          const float drift = (mx_prev > kNegThresh) ? (mx - mx_prev) + (float)step_k : 0.0f;
-          step_3 = min(max((int)__builtin_rintf(mx + 2.5f * drift) - step_1 - step_2, -kStepMax), kStepMax);
-        }
-        mx_prev = mx;
-#ifdef FTR_EXP_NOFRAMES   // study build: no renormalisation
-        step_3 = 0;
-#endif
-        if (lane == 0) sring[(k + 3) & 7] = (float)step_3;
-        frame_k += step_1; step_k = step_1; step_1 = step_2; step_2 = step_3;
       }
       clear_imported(kc - 1 + LOOK);
       if (k >= 0 && k < klast) {
