@@ -615,9 +615,11 @@ int ftr_pruned_band_fwd_f32(const float* logits, const int32_t* symbols, const i
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  bool gathered = false;   // one pass where the row fits the wave's registers (C % 4 == 0, C <= 1024), else lse + gather kernels
-  rc = lse_rows_band(logits, symbols, ranges, boundary, termination_symbol, delay_penalty, lse, px_band, py_band, B, T, S, C, r, modified, &gathered, st);
-  if (rc != FTR_OK || gathered) return rc;
+  // lse and the band gather are two launches: folding the gather into the lse pass (picking the blank / symbol entries out
+  // of the registers that hold the row) was built and measured -- 93 - 95 us against 73 + 9 at c3: the extra per-row scalar
+  // work (two divisions, the ranges -> symbols dependency) costs the streaming pass more than the second kernel does
+  rc = lse_rows(logits, lse, (size_t)B * T * r, C, st);
+  if (rc != FTR_OK) return rc;
   return band_gather(logits, symbols, ranges, boundary, lse, termination_symbol, delay_penalty, px_band, py_band, B, T, S, C, r, modified, st);
 }
 

@@ -146,7 +146,6 @@ int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, c
 int simple_fused_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* prod, const float* lm_probs, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float cs, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
 int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);
 int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st);
-int lse_rows_band(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, bool* gathered, hipStream_t st);
 int mi_band_supported(int T, int S, int r);
 int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st);
 int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, hipStream_t st);

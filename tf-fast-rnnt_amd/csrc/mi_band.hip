@@ -127,6 +127,7 @@ static __device__ unsigned long long g_bstamp[16];
 #define FTR_BSTAMP(k) do {} while (0)
 #endif
 constexpr int kBandAhead = 4;   // steps per operand fetch group
+constexpr int kRenormEvery = 4;  // the chains renormalise every kRenormEvery iterations of 2 kBandAhead steps (a power of two)
 template <int LANES>
 __host__ __device__ inline size_t band_lds_bytes(int T, int S) {
   const size_t ncap = ((size_t)S + T + 5 + 4 * kBandAhead) * LANES;
@@ -321,12 +322,13 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
       G[slot] = (d >= 0.0f) ? rc : ex * rc;
     };
-    // Renormalisation ("frames", as in mi_wave_bidir.hip): every 2 U steps the chain's values are brought back to the
+    // Renormalisation ("frames", as in mi_wave_bidir.hip): every 32 steps the chain's values are brought back to the
     // neighbourhood of zero by an integer shift, the same for all lanes of the chain (a uniform shift of an anti-diagonal
     // changes no split ratio), so that float32 keeps its resolution whatever the magnitude of the log-probabilities -- the
-    // static shift above only removes what the band's MEAN transition predicts.  The maximum is taken from a copy made one
-    // iteration earlier, off the dependent chain; on the chain it costs one subtraction per 2 U steps.  frame = what has
-    // been subtracted so far, added back on the cut.
+    // static shift above only removes what the band's MEAN transition predicts.  The maximum is taken from a copy made 2 U
+    // steps earlier; on the chain it costs one subtraction, but the four dependent DPP maxima in front of it are not free on
+    // a lone in-order wave (every 8 steps they cost the LDS kernel 8 % and the streaming kernel 24 %), hence every 32.
+    // frame = what has been subtracted so far, added back on the cut.
     float frame = 0.0f;
     auto renorm = [&](float snap) {   // snap: this lane's value 2 U steps ago (no shift in between: the same frame)
       const float mx = row16_max(snap);
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
       int i = 0;
       for (; i + 2 * U <= n1; i += 2 * U) {
         const int sl = base1 + i * LANES;
+        const bool rn = ((i / (2 * U)) & (kRenormEvery - 1)) == kRenormEvery - 1;   // every 2 U kRenormEvery steps
         const float snap = val;
 #pragma unroll
         for (int u = 0; u < U; ++u) ob[u] = O2[sl + (U + u) * LANES];
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_kernel(
         for (int u = 0; u < U; ++u) oa[u] = O2[sl + (2 * U + u) * LANES];
 #pragma unroll
         for (int u = 0; u < U; ++u) fwd(sl + (U + u) * LANES, ob[u]);
-        renorm(snap);
+        if (rn) renorm(snap);
       }
       for (; i < n1; ++i) fwd(base1 + i * LANES, O2[base1 + i * LANES]);
     }
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
       const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
       G[slot] = (d >= 0.0f) ? rc : ex * rc;
     };
-    // renormalisation of the chains' values every 2 U steps, see the LDS kernel
+    // renormalisation of the chains' values twice per block of P = 48 steps, see the LDS kernel
     float frame = 0.0f;
     auto renorm = [&](float snap) {
       const float mx = row16_max(snap);
@@ -622,12 +625,12 @@ __global__ __launch_bounds__(kBandThreads) void mi_band_stream_kernel(
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
           const int kf = (k + NS - 1) % NS;                     // the set NS - 1 groups ahead
-          if ((k & 1) == 0) snap = val;
+          if (k == NS / 2 - 2 || k == NS - 2) snap = val;
 #pragma unroll
           for (int u = 0; u < U; ++u) o[kf][u] = O2[base1 + (i + (k + NS - 1) * U + u) * LANES];
 #pragma unroll
           for (int u = 0; u < U; ++u) fwd(base1 + (i + k * U + u) * LANES, o[k][u]);
-          if ((k & 1) == 1) renorm(snap);
+          if (k == NS / 2 - 1 || k == NS - 1) renorm(snap);   // every 24 steps, from a copy 8 steps old
         }
       }
     }

@@ -16,16 +16,9 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // logsumexp of each row, the row held in registers (C % 4 == 0, C <= 256 * NQ): one 16-byte load per lane and quad,
 // all of a wave's loads (RW rows x NQ quads) issued before the first is used, a single pass over the data.
-// Optional band gather (GATHER; the band path of rnnt_loss_pruned): while a row is in registers its blank and symbol entries
-// are picked out of them and px_band / py_band (mi_band.hip: band_gather_kernel, the same formulas) are written by the
-// same pass -- no second kernel re-reading two elements of every 2 KB row.
-struct BandGather {
-  const int32_t* symbols; const int32_t* ranges; const int32_t* boundary;
-  float* pxb; float* pyb; double delay_penalty; int blank, T, S, r, modified;
-};
-template <int NQ, int RW, bool GATHER>
+template <int NQ, int RW>
 __global__ __launch_bounds__(256) void lse_rows_reg_kernel(const float* __restrict__ logits, float* __restrict__ lse,
-                                                           size_t rows, int C, const BandGather bg) {
+                                                           size_t rows, int C) {
   // persistent waves: RW rows per pass, the next pass's rows are requested before this pass is reduced
   const int lane = threadIdx.x & 63;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -58,38 +51,7 @@ __global__ __launch_bounds__(256) void lse_rows_reg_kernel(const float* __restri
           sum += __expf(v[w][q][0] - m) + __expf(v[w][q][1] - m) + __expf(v[w][q][2] - m) + __expf(v[w][q][3] - m);
       }
       sum = wave_sum(sum);
-      const float l = m + __logf(sum);
-      if (lane == 0 && row0 + w < rows) lse[row0 + w] = l;
-      if (GATHER && row0 + w < rows) {
-        // the element of column c sits in lane (c / 4) % 64, quad (c / 4) / 64, component c % 4: all wave-uniform
-        auto pick = [&](int c) {
-          const int qi = (c >> 2) >> 6, ei = c & 3;
-          float cand = 0.0f;
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cand = (q == qi && e == ei) ? v[w][q][e] : cand;
-          return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), (c >> 2) & 63));
-        };
-        const size_t row = row0 + w;                                   // wave-uniform
-        const size_t bt = row / (size_t)bg.r;
-        const int k = (int)(row - bt * bg.r);
-        const int b = (int)(bt / (size_t)bg.T);
-        const int t = (int)(bt - (size_t)b * bg.T);
-        const int s = bg.ranges[bt * bg.r] + k;
-        const int te = bg.boundary ? bg.boundary[4 * b + 3] : bg.T;
-        float vy = -INFINITY, vx = -INFINITY;
-        if (s >= 0 && s <= bg.S) {
-          vy = pick(bg.blank) - l;
-          if (s < bg.S) {
-            const int sym = __builtin_amdgcn_readfirstlane(min(max(bg.symbols[(size_t)b * bg.S + s], 0), C - 1));
-            vx = pick(sym) - l;
-            if (!bg.modified && t == te) vx = -INFINITY;
-            if (bg.delay_penalty > 0.0) vx += (float)((((double)te - 1.0) / 2.0 - (double)t) * bg.delay_penalty);
-          }
-        }
-        if (lane == 0) { bg.pxb[row] = vx; bg.pyb[row] = vy; }
-      }
+      if (lane == 0 && row0 + w < rows) lse[row0 + w] = m + __logf(sum);
     }
   };
   // two register sets used in turn (no copies): while one is reduced the other one's loads are in flight
@@ -263,44 +225,20 @@ int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream
 }
 
 // logsumexp over the last axis of [rows, C] (rnnt_loss.py:942): picks the register-resident kernel where it fits
-namespace {
-int lse_rows_impl(const float* logits, float* lse, size_t rows, int C, const BandGather* bg, bool* gathered, hipStream_t st);
-}
 int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st) {
-  return lse_rows_impl(logits, lse, rows, C, nullptr, nullptr, st);
-}
-// lse + the band gather in one pass where the register-resident kernel covers C; *gathered tells the caller whether px_band /
-// py_band were written (otherwise it launches band_gather)
-int lse_rows_band(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank,
-                  double delay_penalty, float* lse, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified,
-                  bool* gathered, hipStream_t st) {
-  const BandGather bg{symbols, ranges, boundary, pxb, pyb, delay_penalty, blank, T, S, r, modified};
-  return lse_rows_impl(logits, lse, (size_t)B * T * r, C, &bg, gathered, st);
-}
-namespace {
-int lse_rows_impl(const float* logits, float* lse, size_t rows, int C, const BandGather* bgp, bool* gathered, hipStream_t st) {
-  if (gathered) *gathered = false;
   if (rows == 0) return FTR_OK;
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
   constexpr int RW = 2;
   const size_t want = (rows + (size_t)wpb * RW - 1) / ((size_t)wpb * RW);
   const unsigned blocks_reg = (unsigned)(want < 2048 ? want : 2048);   // 8 blocks of 4 waves per CU, grid-stride
-  const BandGather none{};
-#define FTR_LSE_REG(NQV)                                                                                                                     \
-  do {                                                                                                                                       \
-    if (bgp) { hipLaunchKernelGGL((lse_rows_reg_kernel<NQV, RW, true>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C, *bgp); *gathered = true; } \
-    else hipLaunchKernelGGL((lse_rows_reg_kernel<NQV, RW, false>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C, none);     \
-  } while (0)
-  if ((C & 3) == 0 && C <= 256) FTR_LSE_REG(1);
-  else if ((C & 3) == 0 && C <= 512) FTR_LSE_REG(2);
-  else if ((C & 3) == 0 && C <= 1024) FTR_LSE_REG(4);
+  if ((C & 3) == 0 && C <= 256) hipLaunchKernelGGL((lse_rows_reg_kernel<1, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 512) hipLaunchKernelGGL((lse_rows_reg_kernel<2, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 1024) hipLaunchKernelGGL((lse_rows_reg_kernel<4, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else if ((C & 3) == 0) hipLaunchKernelGGL(lse_rows_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else hipLaunchKernelGGL(lse_rows_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
-#undef FTR_LSE_REG
   return check_launch("lse_rows");
 }
-}  // namespace
 
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges,
                         const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px,
