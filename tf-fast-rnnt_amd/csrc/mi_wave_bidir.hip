@@ -102,6 +102,13 @@ __host__ __device__ inline size_t lattice_floats(int B, int S, int T) {
 }
 
 // COMM wave helpers -----------------------------------------------------------------
+// One granule to the band below: a relaxed agent-scope atomic store (write-through).  (A plain store, which stays in the
+// XCD's L2 where an sc1 poll of a consumer on the same XCD finds it, was measured in round 3 -- all bands of a chain do share
+// an XCD at B = 32 -- and is SLOWER: 58.6 / 49.5 us against 50.5 / 38.7 warm, 66.6 / 61.0 against 58.4 / 52.6 inside the step,
+// profiles/r03_plainpub_experiment.log.  A plain store is visible to nobody until it has left the CU.)
+__device__ __forceinline__ void publish_granule(u64* p, u64 g) {
+  __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ u64 comm_peek(const u64* gran_in, int m, int lane) {
   return __hip_atomic_load(gran_in + CH * m + (lane & (CH - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -719,7 +726,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
           const float v = tp[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
           const unsigned tag = (unsigned)(k + 1) | ((unsigned)step_k << 16);   // 16-bit signed step above the chunk number
           const u64 g = ((u64)tag << 32) | (u64)__float_as_uint(v);
-          __hip_atomic_store(gran_out + CH * k + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          publish_granule(gran_out + CH * k + lane, g);
         }
         if (k == jl / CH) {   // this band's values on the cut (local step jl) and the frame they are in
           if (lane_valid) pmid_store(pmid_b + 64 * w + lane, tp[((((jl & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jl & 3)]);
@@ -1258,7 +1265,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
           const float* txo = reinterpret_cast<const float*>(FTR_TXO(k));
           const float v = txo[(((lane >> 2) * PLANE + 63) << 2) + (lane & 3)];
           const u64 g = ((u64)(unsigned)(k + 1) << 32) | (u64)__float_as_uint(v);
-          __hip_atomic_store(gran_out + CH * k + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          publish_granule(gran_out + CH * k + lane, g);
         }
         if (check && k == (jfin >> 4) && lane == lfin) {   // p_grad at the origin = both inflows (the self check)
           const int idx = ((((jfin & (CH - 1)) >> 2) * PLANE + lane) << 2) + (jfin & 3);
