@@ -154,7 +154,7 @@ CALL_KERNELS = {
     "ftr_prune_ranges_i32": ["prune_argmax_once_kernel<5>", "prune_adjust_kernel"],
     "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
-    "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_chunk_kernel<true>", "do_pruning_bwd_reduce_kernel"],
+    "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_seg_kernel<5, true>", "do_pruning_bwd_reduce_kernel"],
     "ftr_pruned_logprobs_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_to_lattice_kernel<false>"],
     "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_gather_kernel<false>"],
     "ftr_mutual_information_band_f32": ["mi_band_kernel<false, 8>"],
@@ -424,6 +424,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the extra hipGraph-replay measurement")
+    ap.add_argument("--no-dense", action="store_true",
+                    help="skip the secondary dense-am_pruned steps (profiling runs: keeps per-kernel averages to the timed path)")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave rocBLAS' default kernel choice for the three normaliser GEMMs (tf_fast_rnnt.tune_normalizer_gemms)")
     ap.add_argument("--gemm-choices", default=None, help="file the library-GEMM kernel choices are stored in / reloaded from")
@@ -511,7 +513,7 @@ def main():
     # secondary: the same step with am_pruned MATERIALISED ([B,T,r,C] written by the gather and read by the joiner), which is
     # what the reference's tf.broadcast_to costs and what a TensorFlow binding of the C ABI pays; untimed for `value`
     dense_ms = None
-    if which == "pipeline" and world == 1:
+    if which == "pipeline" and world == 1 and not args.no_dense:
         for _ in range(2):
             step(dense=True)
         torch.cuda.synchronize()

@@ -394,9 +394,9 @@ def test_native_joint_builder_and_unpruned_loss(ft, dev, oracle, rnnt_type):
 @pytest.mark.parametrize("same_tensor", [True, False])
 @pytest.mark.parametrize("kind", ["monotone", "scattered", "wide"])
 def test_do_pruning_backward_chunked(ft, dev, kind, same_tensor):
-    """The chunked (workspace) backward of the prune gather on caller-chosen ranges: monotone bands (bins path),
-    rows scattered over the whole lattice and bands wider than the bin budget (both take the overflow path of
-    pass 2), with the two incoming gradients being one tensor (fused d_am) or two.  float64 segment sums as reference;
+    """The segmented (workspace) backward of the prune gather on caller-chosen ranges: monotone bands (window path),
+    rows scattered over the whole lattice and bands that jump back (both take the rescan path of pass 2), with the two
+    incoming gradients being one tensor (fused d_am) or two.  float64 segment sums as reference;
     tolerance 1e-5 relative (f32 sums in a different association)."""
     B, T, S1, C, r = 3, 70, 40, 24, 5
     g = torch.Generator(device="cpu").manual_seed(17)
@@ -423,6 +423,53 @@ def test_do_pruning_backward_chunked(ft, dev, kind, same_tensor):
     want = torch.zeros((B, S1, C), dtype=torch.float64, device=dev)
     want.index_put_((torch.arange(B, device=dev).view(B, 1, 1).expand(B, T, r), ranges.long()), w2.double(), accumulate=True)
     np.testing.assert_allclose(lm.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["flat_then_steep", "gaps", "half_garbage", "owner_conflict", "out_of_range"])
+@pytest.mark.parametrize("shape", [(3, 150, 60, 24, 5), (2, 90, 50, 520, 3), (2, 64, 80, 40, 10), (1, 50, 90, 16, 17)])
+def test_do_pruning_backward_segments(ft, dev, kind, shape, monkeypatch):
+    """The segmented backward of the prune gather (csrc/prune.hip): rows a segment owns go straight to d lm, rows shared
+    with a neighbour through partial rows, everything that is not a band through the rescan of pass 2.  Shapes: several
+    segments, more than 128 column quads (two sweeps), windows of 16 and 32 rows; 16-frame segments forced so that the
+    small T still has many.  float64 segment sums as reference."""
+    monkeypatch.setenv("FTR_PRUNE_SEG", "16")
+    B, T, S1, C, r = shape
+    g = torch.Generator(device="cpu").manual_seed(23)
+    top = S1 - r
+    if kind == "flat_then_steep":        # what random occupancies give: the same rows for most frames, then r-1 rows per frame
+        s0 = torch.zeros((B, T), dtype=torch.int64)
+        climb = torch.clamp((torch.arange(T) - (T - top // max(r - 1, 1) - 3)) * max(r - 1, 1), 0, top)
+        s0 += climb
+    elif kind == "gaps":                 # monotone, but frames jump over rows nobody touches
+        s0 = torch.clamp(torch.cumsum((torch.rand((B, T), generator=g) < 0.1).long() * (r + 3), 1), 0, top)
+    elif kind == "half_garbage":         # a band in the first half of the frames, arbitrary rows in the second
+        s0 = torch.sort(torch.randint(0, top + 1, (B, T), generator=g), dim=1).values
+    elif kind == "owner_conflict":       # every segment is a band, but a later one returns to rows an earlier one owns
+        s0 = torch.sort(torch.randint(0, top + 1, (B, T), generator=g), dim=1).values
+        s0[:, T // 2:] = torch.sort(torch.randint(0, top + 1, (B, T - T // 2), generator=g), dim=1).values
+    else:                                # rows outside [0, S1): ignored, must not fault
+        s0 = torch.sort(torch.randint(0, top + 1, (B, T), generator=g), dim=1).values
+    ranges = (s0.unsqueeze(2) + torch.arange(r)).clone()
+    if kind == "half_garbage":
+        ranges[:, T // 2:] = torch.randint(0, S1, (B, T - T // 2, r), generator=g)
+    ranges = ranges.to(torch.int32).to(dev)
+    w = torch.randn((B, T, r, C), generator=g).to(dev)
+    idx = ranges.long()
+    if kind == "out_of_range":
+        ranges = ranges.clone(); ranges[:, 5:9] += S1; ranges[:, 20:22] -= 2 * S1
+        idx = ranges.long()
+    d_am = torch.full((B, T, C), float("nan"), device=dev); d_lm = torch.full((B, S1, C), float("nan"), device=dev)
+    L = ft._lib
+    nbytes = int(L.lib().ftr_do_pruning_bwd_workspace_bytes(B, T, S1, C, r))
+    ws = torch.empty((nbytes + 3) // 4, device=dev)
+    L.call("ftr_do_pruning_bwd_ws_f32", w.data_ptr(), w.data_ptr(), ranges.data_ptr(), d_am.data_ptr(), d_lm.data_ptr(),
+           B, T, S1, C, r, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_allclose(d_am.cpu().numpy(), w.double().sum(dim=2).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    want = torch.zeros((B, S1, C), dtype=torch.float64, device=dev)
+    valid = (idx >= 0) & (idx < S1)
+    bi = torch.arange(B, device=dev).view(B, 1, 1).expand(B, T, r)
+    want.index_put_((bi[valid], idx[valid]), w.double()[valid], accumulate=True)
+    np.testing.assert_allclose(d_lm.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize("reduction", ["none", "mean", "sum"])

@@ -405,163 +405,256 @@ __global__ void do_pruning_bwd_lm_kernel(const float* __restrict__ g_lm_p, const
 }
 
 
-// ---- chunked backward of the prune gather (16-byte path, C % 4 == 0): g is streamed exactly once.
-// Pass 1, one block per (utterance, TCH consecutive frames): the TCH*r rows of the chunk are contiguous in memory;
-// thread i owns the column quads i, i+128, ...  and walks the rows in (t,k) order, adding each row into the LDS bin
-// of its lattice row s = ranges[b,t,k] (bins cover [smin, smin+nb) of the chunk; a thread only ever touches its own
-// columns: no atomics, no barriers, fixed order).  When the two incoming gradients are the same tensor (the joiner
-// starts with am_pruned + lm_pruned, so autograd hands the same buffer to both) the sum over k that gives d am is
-// taken from the same registers (FUSE).  The bins go to `partial` [B][nchunks][nbmax][C]; meta = {smin, nb}.
-// A chunk whose rows span more than nbmax lattice rows (a burst of the staircase, or arbitrary caller data) is marked
-// nb = -(span) and left to pass 2, which rescans it for the rows inside its span only.
-// Pass 2, one block per (b,s): adds the (at most a few) partial rows that cover s in chunk order; for chunks marked
-// -1 it scans the chunk's ranges and adds the matching rows of g directly.
-constexpr int TCH = 16;
+// ---- segmented backward of the prune gather (16-byte path, C % 4 == 0, r <= 16): g is streamed exactly once.
+// Pass 1, one block per (utterance, SEG consecutive frames): the SEG*r rows of the segment are contiguous in memory; thread i
+// owns the column quads i, i+128, ... and walks the frames in order, two batches of frames in flight.
+// get_rnnt_prune_ranges produces bands -- ranges[b,t,k] = base[b,t] + k with base non-decreasing in t and no lattice row
+// skipped -- so a thread keeps the r lattice rows of the current frame in REGISTERS (acc[k] = row base + k; no LDS, no
+// atomics, no barriers after the prologue, fixed order): a frame with the same base adds into them; when the base moves up
+// by `step`, the rows below it have received everything this segment has for them and are FLUSHED, the registers shift down.
+// A flushed row goes straight into d lm when no other segment touches it (row > the top row of the frame in front of the
+// segment and < the base of the frame behind it), otherwise into one of at most 2r partial rows of the segment
+// (`partial` [B][nseg][2r][C]: slots [0,r) rows shared with earlier segments, [r,2r) rows shared with later ones only).
+// When the two incoming gradients are the same tensor (the joiner starts with am_pruned + lm_pruned, so autograd hands the
+// same buffer to both) the sum over k that gives d am is taken from the same registers (FUSE).
+// No loop of the streaming part contains a memory instruction under a data-dependent trip count (every flush is R stores under
+// uniform branches), so that the compiler keeps counted s_waitcnt vmcnt(n) and the second batch stays in flight.
+// A segment whose rows are not such a band (arbitrary caller data) is marked irregular and left to pass 2.
+// meta[b][seg] = {lowest row, highest row, top row of the frame in front (or INT_MAX: irregular), base of the frame behind}.
+// Pass 2, one block per (b,s): nothing to do for a row that one segment wrote directly; otherwise it adds the partial rows
+// in segment order, or -- irregular segments, or segments that disagree about who owns the row -- rescans the ranges of the
+// segments that touch the row and adds the matching rows of g directly.
+constexpr int kSegIrregular = INT_MAX;
+#ifndef FTR_SEG_ROWS
+#define FTR_SEG_ROWS 16
+#endif
 
-template <bool FUSE>
-__global__ __launch_bounds__(128) void do_pruning_bwd_chunk_kernel(
-    const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, float* __restrict__ d_am,
-    float* __restrict__ partial, int2* __restrict__ meta, int T, int C, int r, int nbmax) {
-  extern __shared__ __attribute__((aligned(16))) float bins[];   // [nbmax][C], then int rs[TCH * r]
-  __shared__ int red[4];
-  int* rs = reinterpret_cast<int*>(bins + (size_t)nbmax * C);
-  const int chunk = blockIdx.x, b = blockIdx.y, nchunks = gridDim.x;
-  const int t0 = chunk * TCH;
-  const int nf = min(TCH, T - t0);
+template <int R, bool FUSE>
+__global__ __launch_bounds__(128) void do_pruning_bwd_seg_kernel(
+    const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, float* __restrict__ d_am, float* __restrict__ d_lm,
+    float* __restrict__ partial, int4* __restrict__ meta, int T, int S1, int C, int SEG) {
+  extern __shared__ int bs[];      // base[SEG]
+  __shared__ int red[8];
+  constexpr int r = R;
+  const int seg = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
+  const int t0 = seg * SEG;
+  const int nf = min(SEG, T - t0);
   const int nrows = nf * r;
   const int32_t* rg = ranges + ((size_t)b * T + t0) * r;
-  int lo = INT_MAX, hi = INT_MIN;
+  // the segment's ranges: lowest / highest row, and is it a band?
+  int lo = INT_MAX, hi = INT_MIN, bad = 0;
   for (int i = threadIdx.x; i < nrows; i += 128) {
     const int v = rg[i];
-    rs[i] = v;
+    const int f = i / r, k = i - f * r;
+    const int v0 = rg[f * r];
     lo = min(lo, v); hi = max(hi, v);
+    bad |= (v != v0 + k) | (v < 0) | (v >= S1);
+    if (k == 0) {
+      bs[f] = v;
+      if (f + 1 < nf) { const int nx = rg[(f + 1) * r]; bad |= (nx < v) | (nx > v + r); }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     lo = min(lo, __shfl_xor(lo, off, 64));
     hi = max(hi, __shfl_xor(hi, off, 64));
+    bad |= __shfl_xor(bad, off, 64);
   }
-  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = lo; red[(threadIdx.x >> 6) * 2 + 1] = hi; }
+  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red[3 * w] = lo; red[3 * w + 1] = hi; red[3 * w + 2] = bad; }
+  if (threadIdx.x == 127) {   // the neighbours (wave 1 writes red[6..7], read after the barrier like the rest)
+    red[6] = t0 > 0 ? rg[-r] + r - 1 : -1;
+    red[7] = t0 + nf < T ? rg[nrows] : INT_MAX - 1;
+  }
   __syncthreads();
-  const int smin = min(red[0], red[2]), smax = max(red[1], red[3]);
-  const int nb = smax - smin + 1;
-  const bool ok = smin >= 0 && nb <= nbmax;
-  // a chunk without bins still records which lattice rows it touches (nb < 0): pass 2 rescans it only for those
-  if (threadIdx.x == 0) meta[(size_t)b * nchunks + chunk] = ok ? make_int2(smin, nb) : make_int2(min(smin, smax), (smin >= 0 && smax >= smin) ? -(smax - smin + 1) : -0x40000000);
+  const int smin = min(red[0], red[3]), smax = max(red[1], red[4]);
+  const int prevtop = red[6], nextbase = red[7];
+  // a band whose neighbours continue it: at most r rows shared with each side
+  const bool ok = !(red[2] | red[5]) && prevtop - (r - 1) <= smin && nextbase >= smax - (r - 1);
+  if (threadIdx.x == 0)
+    meta[(size_t)b * nseg + seg] = make_int4(min(smin, smax), max(smin, smax), ok ? prevtop : kSegIrregular, nextbase);
   if (!ok && !FUSE) return;
   const int n4 = C >> 2;
   const size_t row0 = ((size_t)b * T + t0) * r;
-  for (int c4 = threadIdx.x; c4 < n4; c4 += 128) {
-    f4* mybin = reinterpret_cast<f4*>(bins) + c4;          // bin j at mybin[j * n4]
-    const f4 z = {0.f, 0.f, 0.f, 0.f};
-    if (ok)
-      for (int j = 0; j < nb; ++j) mybin[(size_t)j * n4] = z;
-    const f4u* g = reinterpret_cast<const f4u*>(g_lm_p + row0 * C) + c4;   // row i at g[i * n4]
-    f4 asum = z;
-    int k = 0, f = 0;
-    constexpr int UN = 16;   // rows in flight per thread (16-byte loads): 8 left the kernel at 3.9 TB/s
-    for (int i0 = 0; i0 < nrows; i0 += UN) {
-      f4 v[UN];
+  float* pseg = partial + ((size_t)b * nseg + seg) * (size_t)(2 * r) * C;
+  float* dlm_b = d_lm + (size_t)b * S1 * C;
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  constexpr int FB = (FTR_SEG_ROWS + R - 1) / R;    // frames per batch: about 16 rows; two batches in flight
+  for (int cb = 0; cb < n4; cb += 128) {
+    const int c4 = cb + (int)threadIdx.x;
+    const bool live = c4 < n4;
+    const int cc = live ? c4 : n4 - 1;                       // clamped: every load is issued, what it brings is not stored
+    const f4u* g = reinterpret_cast<const f4u*>(g_lm_p + row0 * C) + cc;   // row i at g[i * n4]
+    f4 acc[R];                                               // lattice rows cur .. cur + R - 1
 #pragma unroll
-      for (int u = 0; u < UN; ++u) v[u] = (i0 + u < nrows) ? (f4)g[(size_t)(i0 + u) * n4] : z;
+    for (int k = 0; k < R; ++k) acc[k] = z;
+    int cur = smin;
+    auto flush = [&](int j) {                                // row cur + j is complete as far as this segment goes
+      const int row = cur + j;
+      // one store instruction per destination buffer (a pointer chosen by ?: becomes a flat access through a pointer table)
+      const int slot = row <= prevtop ? row - smin : r + row - nextbase;
+      if (row <= prevtop || row >= nextbase) {
+        if (live) reinterpret_cast<f4u*>(pseg + (size_t)slot * C)[c4] = acc[j];
+      } else {
+        if (live) reinterpret_cast<f4u*>(dlm_b + (size_t)row * C)[c4] = acc[j];
+      }
+    };
+    auto load = [&](f4 (&v)[FB * R], int f0) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        if (i0 + u < nrows) {
+      for (int u = 0; u < FB * R; ++u) v[u] = g[(size_t)min(f0 * R + u, nrows - 1) * n4];
+    };
+    auto consume = [&](const f4 (&v)[FB * R], int f0) {
+#pragma unroll
+      for (int q = 0; q < FB; ++q) {
+        const int f = f0 + q;
+        if (f < nf) {
           if (ok) {
-            f4* dst = mybin + (size_t)(rs[i0 + u] - smin) * n4;
-            *dst = *dst + v[u];
+            const int step = __builtin_amdgcn_readfirstlane(bs[f]) - cur;   // 0 ... R in a band
+            if (step > 0) {
+#pragma unroll
+              for (int j = 0; j < R; ++j)
+                if (j < step) flush(j);
+              for (int sft = 0; sft < step; ++sft) {          // registers only: no memory instruction in this loop
+#pragma unroll
+                for (int k = 0; k + 1 < R; ++k) acc[k] = acc[k + 1];
+                acc[R - 1] = z;
+              }
+              cur += step;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc[k] += v[q * R + k];
           }
           if (FUSE) {
-            asum += v[u];
-            if (++k == r) {
-              reinterpret_cast<f4u*>(d_am + ((size_t)b * T + t0 + f) * C)[c4] = asum;
-              asum = z; k = 0; ++f;
-            }
+            f4 asum = v[q * R];
+#pragma unroll
+            for (int k = 1; k < R; ++k) asum += v[q * R + k];
+            if (live) reinterpret_cast<f4u*>(d_am + ((size_t)b * T + t0 + f) * C)[c4] = asum;
           }
         }
       }
+    };
+    f4 va[FB * R], vb[FB * R];
+    load(va, 0);
+    for (int f0 = 0; f0 < nf; f0 += 2 * FB) {
+      load(vb, f0 + FB);
+      consume(va, f0);
+      load(va, f0 + 2 * FB);
+      consume(vb, f0 + FB);
     }
     if (ok) {
-      f4u* out = reinterpret_cast<f4u*>(partial + ((size_t)b * nchunks + chunk) * nbmax * C) + c4;
-      for (int j = 0; j < nb; ++j) out[(size_t)j * n4] = mybin[(size_t)j * n4];
+#pragma unroll
+      for (int j = 0; j < R; ++j) flush(j);
     }
   }
 }
 
 // items of the reduction list: bit 31 clear = row index into `partial`, bit 31 set = row index into g_lm_p
 constexpr int RED_CAP = 512;
-// One WAVE per (b,s) (no barriers: a wave is in lock step): it lists the chunks that hold something for its row with
-// ballots, expands them into row items in (chunk, t, k) order -- a chunk with bins gives one partial row, a chunk
-// without is scanned here, 128 of its rows per pass -- and adds the rows, four loads in flight.
-__global__ __launch_bounds__(64) void do_pruning_bwd_reduce_kernel(
+#ifndef FTR_RED_WAVES
+#define FTR_RED_WAVES 2
+#endif
+constexpr int RED_WAVES = FTR_RED_WAVES;   // 1, 2 or 4 (c3 / c4 / c5 with 128-frame segments: 8.4 / 16.0 / 27.4, 8.6 / 15.1 / 22.9, 11.0 / 18.2 / 21.8 us)
+// One block of RED_WAVES waves per (b,s).  Wave 0 lists the segments that touch the row with ballots and decides: nobody -> zeros;
+// one band segment that owns the row -> pass 1 has written it; band segments that all hold a partial row for it -> those, in
+// segment order; anything else (an irregular segment, or band segments that disagree about the owner: only caller data that is
+// not a band does that) -> the ranges of the touching segments are rescanned, 128 rows per pass, and the matching rows of g are
+// the items.  Then wave w adds the items w, w + RED_WAVES, ... (four loads in flight) and the sums are combined as
+// w0 + w1 (or (w0 + w1) + (w2 + w3)): a fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(64 * RED_WAVES) void do_pruning_bwd_reduce_kernel(
     const float* __restrict__ g_lm_p, const int32_t* __restrict__ ranges, const float* __restrict__ partial,
-    const int2* __restrict__ meta, float* __restrict__ d_lm, int T, int S1, int C, int r, int nbmax, int nchunks) {
-  extern __shared__ int hits[];    // [3 * nchunks]: chunk id, first row (or first lattice row), span (< 0: no bins)
+    const int4* __restrict__ meta, float* __restrict__ d_lm, int T, int S1, int C, int r, int SEG, int nseg) {
+  extern __shared__ __attribute__((aligned(16))) int dyn[];   // hits [2 * nseg], then (16-byte aligned) sums [RED_WAVES - 1][256] quads
   __shared__ unsigned items[RED_CAP];
+  __shared__ int ctl[4];           // nh (or -1: nothing to do), hi, j0, cnt of the batch
+  int* hits = dyn;                 // segment id, partial slot of the row (or -1: rescan the segment)
+  f4* sums = reinterpret_cast<f4*>(dyn + ((2 * nseg + 3) & ~3));
   const int s = blockIdx.x, b = blockIdx.y;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const int2* mb = meta + (size_t)b * nchunks;
-  int nh = 0;
-  for (int c0 = 0; c0 < nchunks; c0 += 64) {
-    const int ch = c0 + lane;
-    bool hit = false;
-    int2 m = make_int2(0, 0);
-    if (ch < nchunks) {
-      m = mb[ch];
-      const int span = m.y < 0 ? -m.y : m.y;
-      hit = m.y != 0 && (m.y == -0x40000000 || (s >= m.x && s - m.x < span));
-    }
-    const unsigned long long mask = __ballot(hit);
-    if (hit) {
-      const int pos = nh + __popcll(mask & lt);
-      hits[3 * pos] = ch; hits[3 * pos + 1] = m.x; hits[3 * pos + 2] = m.y;
-    }
-    nh += __popcll(mask);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wave: LDS accesses execute in program order,
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the fences only keep the compiler from reordering them
   const int n4 = C >> 2;
-  float* out = d_lm + ((size_t)b * S1 + s) * C;
-  for (int cb = 0; cb < n4; cb += 256) {   // 4 column quads per lane and sweep (one sweep for C <= 1024)
-    f4 acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
-    int hi = 0, j0 = 0;
-    while (hi < nh) {
-      int cnt = 0;
-      while (hi < nh && cnt <= RED_CAP - 128) {
-        const int ch = hits[3 * hi], mx = hits[3 * hi + 1], my = hits[3 * hi + 2];
-        if (my > 0) {
-          if (lane == 0) items[cnt] = (unsigned)(((size_t)b * nchunks + ch) * nbmax + (s - mx));
-          ++cnt; ++hi;
-        } else {
-          const int t0 = ch * TCH;
-          const int nrows = min(TCH, T - t0) * r;
-          const size_t row0 = ((size_t)b * T + t0) * r;
-          while (j0 < nrows && cnt <= RED_CAP - 128) {
-            const int ja = j0 + lane, jb = j0 + 64 + lane;          // two independent loads per pass
-            const int va = ja < nrows ? ranges[row0 + ja] : -1;
-            const int vb = jb < nrows ? ranges[row0 + jb] : -1;
-            const unsigned long long ma = __ballot(va == s), mk = __ballot(vb == s);
-            if (va == s) items[cnt + __popcll(ma & lt)] = 0x80000000u | (unsigned)(row0 + ja);
-            cnt += __popcll(ma);
-            if (vb == s) items[cnt + __popcll(mk & lt)] = 0x80000000u | (unsigned)(row0 + jb);
-            cnt += __popcll(mk);
-            j0 += 128;
-          }
-          if (j0 >= nrows) { ++hi; j0 = 0; }
+  if (wv == 0) {
+    const int4* mb = meta + (size_t)b * nseg;
+    int nh = 0, ndirect = 0, nresc = 0;
+    for (int c0 = 0; c0 < nseg; c0 += 64) {
+      const int sg = c0 + lane;
+      bool hit = false, direct = false, resc = false;
+      int slot = -1;
+      if (sg < nseg) {
+        const int4 m = mb[sg];
+        hit = s >= m.x && s <= m.y;
+        if (hit) {
+          if (m.z == kSegIrregular) resc = true;
+          else if (s <= m.z) slot = s - m.x;
+          else if (s >= m.w) slot = r + s - m.w;
+          else direct = true;
         }
       }
-      // LDS writes above are visible to the whole wave after the waitcnt the compiler places before the reads below
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      int i = 0;
-      for (; i + 3 < cnt; i += 4) {
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int pos = nh + __popcll(mask & lt);
+        hits[2 * pos] = sg; hits[2 * pos + 1] = slot;
+      }
+      nh += __popcll(mask);
+      ndirect += __popcll(__ballot(direct));
+      nresc += __popcll(__ballot(resc));
+    }
+    const bool done = nh == 1 && ndirect == 1;                 // pass 1 wrote the row
+    const bool rescan = !done && (nresc > 0 || ndirect > 0);   // not (only) bands: take every touching segment from g
+    if (rescan)
+      for (int i = lane; i < nh; i += 64) hits[2 * i + 1] = -1;
+    if (lane == 0) { ctl[0] = done ? -1 : nh; ctl[1] = 0; ctl[2] = 0; }
+  }
+  __syncthreads();
+  const int nh = ctl[0];
+  if (nh < 0) return;
+  float* out = d_lm + ((size_t)b * S1 + s) * C;
+  f4 tot[4];                       // wave 0's lanes: the row's running total over the batches (4 column quads per lane and sweep)
+  for (int cb = 0; cb < n4; cb += 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tot[q] = f4{0.f, 0.f, 0.f, 0.f};
+    if (wv == 0 && lane == 0) { ctl[1] = 0; ctl[2] = 0; }
+    __syncthreads();
+    while (true) {
+      // ---- wave 0: the next batch of items
+      if (wv == 0) {
+        int hi = ctl[1], j0 = ctl[2], cnt = 0;
+        while (hi < nh && cnt <= RED_CAP - 128) {
+          const int sg = hits[2 * hi], slot = hits[2 * hi + 1];
+          if (slot >= 0) {
+            if (lane == 0) items[cnt] = (unsigned)(((size_t)b * nseg + sg) * (2 * r) + slot);
+            ++cnt; ++hi;
+          } else {
+            const int t0 = sg * SEG;
+            const int nrows = min(SEG, T - t0) * r;
+            const size_t row0 = ((size_t)b * T + t0) * r;
+            while (j0 < nrows && cnt <= RED_CAP - 128) {
+              const int ja = j0 + lane, jb = j0 + 64 + lane;          // two independent loads per pass
+              const int va = ja < nrows ? ranges[row0 + ja] : -1;
+              const int vb = jb < nrows ? ranges[row0 + jb] : -1;
+              const unsigned long long ma = __ballot(va == s), mk = __ballot(vb == s);
+              if (va == s) items[cnt + __popcll(ma & lt)] = 0x80000000u | (unsigned)(row0 + ja);
+              cnt += __popcll(ma);
+              if (vb == s) items[cnt + __popcll(mk & lt)] = 0x80000000u | (unsigned)(row0 + jb);
+              cnt += __popcll(mk);
+              j0 += 128;
+            }
+            if (j0 >= nrows) { ++hi; j0 = 0; }
+          }
+        }
+        if (lane == 0) { ctl[1] = hi; ctl[2] = j0; ctl[3] = cnt; }
+      }
+      __syncthreads();
+      const int cnt = ctl[3];
+      const bool last = ctl[1] >= nh;
+      // ---- every wave: its share of the batch
+      f4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+      int i = wv;
+      for (; i + 3 * RED_WAVES < cnt; i += 4 * RED_WAVES) {
         const float* src[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const unsigned it = items[i + u];
+          const unsigned it = items[i + u * RED_WAVES];
           src[u] = (it & 0x80000000u) ? g_lm_p + (size_t)(it & 0x7fffffffu) * C : partial + (size_t)it * C;
         }
         f4 v[4][4];
@@ -577,7 +670,7 @@ __global__ __launch_bounds__(64) void do_pruning_bwd_reduce_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q] += v[u][q];
       }
-      for (; i < cnt; ++i) {
+      for (; i < cnt; i += RED_WAVES) {
         const unsigned it = items[i];
         const float* src = (it & 0x80000000u) ? g_lm_p + (size_t)(it & 0x7fffffffu) * C : partial + (size_t)it * C;
 #pragma unroll
@@ -586,19 +679,54 @@ __global__ __launch_bounds__(64) void do_pruning_bwd_reduce_kernel(
           if (c4 < n4) acc[q] += reinterpret_cast<const f4u*>(src)[c4];
         }
       }
-    }
+      if (RED_WAVES > 1 && cnt > 1) {   // uniform over the block: a single item is wave 0's alone
+        if (wv != 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c4 = cb + lane + 64 * q;
-      if (c4 < n4) reinterpret_cast<f4u*>(out)[c4] = acc[q];
+          for (int q = 0; q < 4; ++q) {
+            const int c4 = lane + 64 * q;
+            if (cb + c4 < n4) sums[(size_t)(wv - 1) * 256 + c4] = acc[q];
+          }
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c4 = lane + 64 * q;
+            if (cb + c4 < n4) tot[q] += RED_WAVES == 4 ? (acc[q] + sums[c4]) + (sums[256 + c4] + sums[512 + c4]) : acc[q] + sums[c4];
+          }
+        }
+      } else if (wv == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tot[q] += acc[q];
+      }
+      if (last) break;
+      __syncthreads();             // the batch's items and sums are consumed: wave 0 may overwrite them
     }
+    if (wv == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c4 = cb + lane + 64 * q;
+        if (c4 < n4) reinterpret_cast<f4u*>(out)[c4] = tot[q];
+      }
+    }
+    __syncthreads();
   }
 }
 
-inline int chunk_nbmax(int C) {
-  const int n = (64 * 1024) / (4 * (C > 0 ? C : 1));
-  return n < 4 ? 4 : (n > 16 ? 16 : n);
+// frames per segment: a block per CU and more (two 16-row batches in flight per thread keep a wave busy: measured at c3, pass 1
+// takes 80 - 83 us with anything from 4 to 128 frames per segment, i.e. 8000 to 256 blocks), as long as possible otherwise:
+// every segment costs up to 2r partial rows where the band is flat, and pass 2 one addition per segment and shared row
+// (c3: 71 / 36 / 22 / 11 us with 4 / 8 / 16 / 128 frames)
+inline int seg_frames(int B, int T) {
+  const char* e = getenv("FTR_PRUNE_SEG");   // study / test knob, read per call (one getenv per launch)
+  const int forced = e ? atoi(e) : 0;
+  if (forced >= 4) return forced;
+  const long long per = ((long long)B * T + 255) / 256;
+  int seg = 16;
+  while (seg < per && seg < 128) seg <<= 1;
+  return seg;
 }
+constexpr int kSegMaxR = 16;   // widest band the register window is instantiated for; wider ones take the generic kernels
 
 }  // namespace
 
@@ -667,10 +795,11 @@ int do_pruning(const float* am, const float* lm, const int32_t* ranges, float* a
 }
 
 size_t do_pruning_bwd_workspace_bytes(int B, int T, int S1, int C, int r) {
-  if ((C & 3) != 0 || (size_t)B * T * C == 0) return 0;
-  const size_t nchunks = (size_t)(T + ftr::TCH - 1) / ftr::TCH;
-  const size_t partial = sizeof(float) * (size_t)B * nchunks * ftr::chunk_nbmax(C) * C;
-  return partial + sizeof(int2) * (size_t)B * nchunks;
+  if ((C & 3) != 0 || (size_t)B * T * C == 0 || r <= 0) return 0;
+  const int seg = ftr::seg_frames(B, T);
+  const size_t nseg = (size_t)(T + seg - 1) / seg;
+  const size_t partial = sizeof(float) * (size_t)B * nseg * (2 * (size_t)r) * C;
+  return partial + sizeof(int4) * (size_t)B * nseg;
 }
 
 int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* ranges, float* d_am, float* d_lm,
@@ -682,30 +811,33 @@ int do_pruning_bwd_ws(const float* g_am_p, const float* g_lm_p, const int32_t* r
     set_error("do_pruning_bwd_ws: workspace of %zu bytes (16-byte aligned) required, got %zu", need, ws_bytes);
     return FTR_ERR_INVALID_ARG;
   }
-  const int nbmax = ftr::chunk_nbmax(C);
-  const int nchunks = (T + ftr::TCH - 1) / ftr::TCH;
+  const int seg = ftr::seg_frames(B, T);
+  const int nseg = (T + seg - 1) / seg;
   float* partial = reinterpret_cast<float*>(ws);
-  int2* meta = reinterpret_cast<int2*>(partial + (size_t)B * nchunks * nbmax * C);
-  const size_t lds = sizeof(float) * (size_t)nbmax * C + sizeof(int) * (size_t)ftr::TCH * r;
-  if (lds > 150 * 1024) return do_pruning_bwd(g_am_p, g_lm_p, ranges, d_am, d_lm, B, T, S1, C, r, st);
+  int4* meta = reinterpret_cast<int4*>(partial + (size_t)B * nseg * (2 * (size_t)r) * C);
+  const size_t lds = sizeof(int) * (size_t)seg;
+  if (r > ftr::kSegMaxR || lds > 60 * 1024 || (size_t)B * nseg * (2 * (size_t)r) >= 0x7fffffffull || (size_t)B * T * r >= 0x7fffffffull)
+    return do_pruning_bwd(g_am_p, g_lm_p, ranges, d_am, d_lm, B, T, S1, C, r, st);
   const bool fuse = (g_am_p == g_lm_p);
-  if (lds > 64 * 1024) {
-    hipError_t e = fuse ? hipFuncSetAttribute(reinterpret_cast<const void*>(ftr::do_pruning_bwd_chunk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                        : hipFuncSetAttribute(reinterpret_cast<const void*>(ftr::do_pruning_bwd_chunk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("do_pruning_bwd_ws: cannot reserve LDS: %s", hipGetErrorString(e)); return FTR_ERR_LAUNCH; }
-  }
   if (!fuse) {
     const size_t total = (size_t)B * T * (C >> 2);
     hipLaunchKernelGGL(ftr::do_pruning_bwd_am_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g_am_p, d_am, C, r, total);
     int rc = check_launch("do_pruning_bwd_am");
     if (rc != FTR_OK) return rc;
-    hipLaunchKernelGGL(ftr::do_pruning_bwd_chunk_kernel<false>, dim3(nchunks, B), dim3(128), lds, st, g_lm_p, ranges, d_am, partial, meta, T, C, r, nbmax);
-  } else {
-    hipLaunchKernelGGL(ftr::do_pruning_bwd_chunk_kernel<true>, dim3(nchunks, B), dim3(128), lds, st, g_lm_p, ranges, d_am, partial, meta, T, C, r, nbmax);
   }
-  int rc = check_launch("do_pruning_bwd_chunk");
+#define FTR_SEG(R) case R: \
+    if (fuse) hipLaunchKernelGGL((ftr::do_pruning_bwd_seg_kernel<R, true>), dim3(nseg, B), dim3(128), lds, st, g_lm_p, ranges, d_am, d_lm, partial, meta, T, S1, C, seg); \
+    else hipLaunchKernelGGL((ftr::do_pruning_bwd_seg_kernel<R, false>), dim3(nseg, B), dim3(128), lds, st, g_lm_p, ranges, d_am, d_lm, partial, meta, T, S1, C, seg); \
+    break;
+  switch (r) {
+    FTR_SEG(1) FTR_SEG(2) FTR_SEG(3) FTR_SEG(4) FTR_SEG(5) FTR_SEG(6) FTR_SEG(7) FTR_SEG(8)
+    FTR_SEG(9) FTR_SEG(10) FTR_SEG(11) FTR_SEG(12) FTR_SEG(13) FTR_SEG(14) FTR_SEG(15) FTR_SEG(16)
+  }
+#undef FTR_SEG
+  int rc = check_launch("do_pruning_bwd_seg");
   if (rc != FTR_OK) return rc;
-  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(64), 3 * sizeof(int) * (size_t)nchunks, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, nbmax, nchunks);
+  hipLaunchKernelGGL(ftr::do_pruning_bwd_reduce_kernel, dim3(S1, B), dim3(64 * ftr::RED_WAVES),
+                     sizeof(int) * (size_t)((2 * nseg + 3) & ~3) + 3 * 256 * sizeof(float) * 4, st, g_lm_p, ranges, partial, meta, d_lm, T, S1, C, r, seg, nseg);
   return check_launch("do_pruning_bwd_reduce");
 }
 

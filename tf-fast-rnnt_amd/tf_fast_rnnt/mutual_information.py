@@ -179,6 +179,7 @@ class _MutualInformation(torch.autograd.Function):
             px_grad = torch.zeros_like(px)
             py_grad = torch.zeros_like(py)
         ctx.mark_non_differentiable(px_grad, py_grad)
+        ctx.set_materialize_grads(False)          # no zero tensors for the two occupancy outputs in backward
         return ans, px_grad, py_grad
 
     @staticmethod
@@ -186,6 +187,8 @@ class _MutualInformation(torch.autograd.Function):
         if not ctx.have_grads:
             raise RuntimeError("mutual_information_recursion: backward without saved occupancies")
         px_grad, py_grad = ctx.saved_tensors
+        if g_ans is None:
+            return None, None, None, None
         g = g_ans.reshape(-1, 1, 1)            # _RNNTLossGrad: ans_grad * gradpx, ans_grad * gradpy
         return g * px_grad, g * py_grad, None, None
 

@@ -200,10 +200,13 @@ class _SimpleLoss(torch.autograd.Function):
         ctx.has_boundary = boundary is not None
         ctx.meta = (int(termination_symbol), int(modified), int(code))
         ctx.mark_non_differentiable(px_grad, py_grad)
+        ctx.set_materialize_grads(False)          # no zero tensors for the two occupancy outputs in backward
         return loss, px_grad, py_grad
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
+        if g_loss is None:
+            return (None,) * 9
         am_probs, lm_probs, prod, symbols, boundary, px_grad, py_grad = ctx.saved_tensors
         if not ctx.has_boundary:
             boundary = None
@@ -930,10 +933,13 @@ class _SmoothedLoss(torch.autograd.Function):
         ctx.meta = meta
         ctx.code = int(code)
         ctx.mark_non_differentiable(px_grad, py_grad)
+        ctx.set_materialize_grads(False)          # no zero tensors for the two occupancy outputs in backward
         return loss, px_grad, py_grad
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
+        if g_loss is None:
+            return (None,) * 12
         *saved, px_grad, py_grad = ctx.saved_tensors
         B = saved[0].shape[0]
         scale, stride, mul = _upstream_scale(g_loss, ctx.code, B)
