@@ -321,6 +321,28 @@ int ftr_smoothed_logprobs_fused_fwd_f32(const float* am, const float* lm, const 
                                         const int32_t* boundary, int termination_symbol, double delay_penalty,
                                         float combined_scale, float lm_only_scale, float am_only_scale, float* px,
                                         float* py, float* prod, int B, int T, int S, int C, int modified, void* stream);
+/* The dense f32 contractions of the simple / smoothed builders that are not inside a hand-written kernel -- what TensorFlow
+ * runs as tf.matmul in rnnt_loss.py:180-182 (and :1270-1272) and as the two matmuls of its autodiff -- as rocBLAS
+ * strided-batched GEMMs on row-major operands:
+ *   kind 0: out [B,S+1,T] = x . y^T   with x = lm_probs [B,S+1,C], y = am_probs [B,T,C]   (forward; only where the fused
+ *           forward kernel does not apply: C % 4 != 0)
+ *   kind 1: out [B,S+1,C] = x . y     with x = W [B,S+1,T],        y = am_probs [B,T,C]   (backward towards lm)
+ *   kind 2: out [B,T,C]   = x^T . y   with x = W [B,S+1,T],        y = lm_probs [B,S+1,C] (backward towards am; where the fused
+ *           d am kernel does not apply)
+ * S1 = S + 1.  The library's kernel for a shape is chosen by measurement: at the SECOND call with the same shape (and never
+ * inside a stream capture) every candidate rocBLAS offers is timed on the caller's stream (~0.2 s, `out` is recomputed by
+ * each) and the fastest one is used from then on, for the life of the process (c3: 90 / 84 us with the library's own choice,
+ * 62 / 60 us with the measured one).  FTR_GEMM_TUNE=off keeps the library's choice, =first measures at the first call.
+ * ftr_normalizer_gemm_choice reports what was chosen for a shape on the current device: returns 1 and fills (any pointer may
+ * be NULL) the rocBLAS solution index (0 = library's own), its time and the default's time in us, and the number of candidates
+ * timed (-1 = not measured yet); 0 if the shape has not been seen.  ftr_normalizer_gemm_set_choice fixes the solution index
+ * for a shape without measuring (a choice recorded by an earlier process on the same rocBLAS; an index the library rejects
+ * falls back to its own choice). */
+int ftr_normalizer_gemm_f32(int kind, const float* x, const float* y, float* out, int B, int T, int S1, int C, void* stream);
+int ftr_normalizer_gemm_choice(int kind, int B, int T, int S1, int C, int* solution, float* us, float* us_default,
+                               int* candidates);
+int ftr_normalizer_gemm_set_choice(int kind, int B, int T, int S1, int C, int solution);
+
 /* Backward towards am with the W^T . lm_probs contraction inside the kernel (f32 MFMA): replaces one of the two backward
  * matmuls AND ftr_*_logprobs_bwd_am_*: W is formed from g_px, g_py and prod while staging, the scatter by symbol runs as a
  * second small MFMA contraction against a one-hot operand, `damp` [B,T,C] never exists.  Scale arguments as in the _scaled

@@ -1,5 +1,7 @@
 """GPU parity of the pruning pipeline and of the loss drivers against the oracle, through the package
 (ctypes -> C ABI -> HIP).  Integer outputs are compared bit-exactly; floats as in test_gpu_mi.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -845,30 +847,45 @@ def test_whole_pipeline_fuzz_against_oracle(ft, dev, oracle):
             assert max_rel(logits.grad.cpu().numpy()[f], o_g[f]) <= 2e-4, (it, B, T, S, C, r, rt)
 
 
-def test_gemm_kernel_selection_switch(ft, dev, tmp_path):
-    """tune_normalizer_gemms (PyTorch TunableOp over rocBLAS / hipBLASLt for the library GEMMs that remain in the builders'
-    backward): switching it on changes which library kernel runs, not the result (1e-5 normwise), the choices land in the
-    given file, and switching it off restores the default."""
-    import torch.cuda.tunable as tunable
-    d = synthetic(5, 2, 70, 33, 24, ragged=True)
-    sym, bd = _t(d["symbols"], dev), _t(d["boundary"], dev)
-
-    def grads():
-        lm = _t(d["lm"], dev).requires_grad_(True); am = _t(d["am"], dev).requires_grad_(True)
-        ft.rnnt_loss_simple(lm, am, sym, d["termination_symbol"], boundary=bd, reduction="sum").backward()
-        return am.grad.cpu().numpy(), lm.grad.cpu().numpy()
-
-    ref = grads()
-    path = str(tmp_path / "gemm_choices.csv")
-    try:
-        ft.tune_normalizer_gemms(True, path)
-        assert tunable.is_enabled() and tunable.tuning_is_enabled() and tunable.get_filename() == path
-        got = grads()
-    finally:
-        ft.tune_normalizer_gemms(False)
-    assert not tunable.is_enabled()
-    for g, r_ in zip(got, ref):
-        assert np.abs(g - r_).max() <= 1e-5 * max(1.0, np.abs(r_).max())
-    again = grads()
-    for g, r_ in zip(again, ref):
-        assert np.array_equal(g, r_)
+def test_gemm_kernel_selection(ft, dev, monkeypatch):
+    """The library GEMMs of the builders' backward (ftr_normalizer_gemm_f32, rocBLAS): against torch.bmm for all three kinds;
+    the kernel is measured at the second call with a shape (default), which changes which library kernel runs, not the
+    result (1e-5 normwise); FTR_GEMM_TUNE=off leaves a new shape unmeasured; a recorded choice can be carried over."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, T, S, C = 3, 72, 33, 40
+    lm_probs = torch.rand((B, S + 1, C), generator=g).to(dev); am_probs = torch.rand((B, T, C), generator=g).to(dev)
+    W = torch.randn((B, S + 1, T), generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    from tf_fast_rnnt.rnnt_loss import _gemm
+    want = (torch.bmm(lm_probs, am_probs.transpose(1, 2)), torch.bmm(W, am_probs), torch.bmm(W.transpose(1, 2), lm_probs))
+    monkeypatch.setenv("FTR_GEMM_TUNE", "second")
+    for kind, (x, y) in enumerate(((lm_probs, am_probs), (W, am_probs), (W, lm_probs))):
+        first = _gemm(kind, x, y, B, T, S, C, st)
+        ch = ft.normalizer_gemm_choice(kind, B, T, S, C)
+        assert ch is not None and ch["candidates"] == -1 and ch["solution"] == 0       # seen once: not measured yet
+        second = _gemm(kind, x, y, B, T, S, C, st)                                     # measures, then runs the winner
+        ch = ft.normalizer_gemm_choice(kind, B, T, S, C)
+        assert ch["candidates"] >= 0 and ch["us_default"] > 0
+        if ch["solution"]:
+            assert ch["us"] <= 0.97 * ch["us_default"]
+        for got in (first, second, _gemm(kind, x, y, B, T, S, C, st)):
+            assert got.shape == want[kind].shape
+            assert (got - want[kind]).abs().max().item() <= 1e-5 * max(1.0, want[kind].abs().max().item())
+    # off: a new shape stays with the library's own kernel however often it runs
+    monkeypatch.setenv("FTR_GEMM_TUNE", "off")
+    for _ in range(3):
+        _gemm(1, W[:2], am_probs[:2], 2, T, S, C, st)
+    assert ft.normalizer_gemm_choice(1, 2, T, S, C)["candidates"] == -1
+    # a recorded choice for a shape that has not run (an index the library rejects falls back to its own kernel)
+    ft.set_normalizer_gemm_choice(1, 1, T, S, C, ft.normalizer_gemm_choice(1, B, T, S, C)["solution"])
+    ft.set_normalizer_gemm_choice(2, 1, T, S, C, 2147483)
+    for kind, y in ((1, am_probs), (2, lm_probs)):
+        got = _gemm(kind, W[:1], y[:1], 1, T, S, C, st)
+        assert (got - want[kind][:1]).abs().max().item() <= 1e-5 * max(1.0, want[kind].abs().max().item())
+    assert ft.normalizer_gemm_choice(2, 1, T, S, C)["solution"] == 0
+    # the switch function only moves the environment variable
+    ft.tune_normalizer_gemms(False)
+    assert os.environ["FTR_GEMM_TUNE"] == "off"
+    ft.tune_normalizer_gemms(True, when="first")
+    assert os.environ["FTR_GEMM_TUNE"] == "first"
+    monkeypatch.delenv("FTR_GEMM_TUNE")

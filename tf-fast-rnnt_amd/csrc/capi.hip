@@ -62,7 +62,7 @@ using namespace ftr;
 
 extern "C" {
 
-int ftr_abi_version(void) { return 130; }
+int ftr_abi_version(void) { return 131; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
@@ -508,6 +508,21 @@ int ftr_smoothed_logprobs_fwd_pen_f32(const float* am, const float* lm, const in
 
 int ftr_simple_logprobs_fused_supported(int C) { return simple_fused_supported(C); }
 int ftr_simple_logprobs_fused_bwd_supported(int T, int C) { return simple_fused_bwd_supported(T, C); }
+
+int ftr_normalizer_gemm_f32(int kind, const float* x, const float* y, float* out, int B, int T, int S1, int C, void* stream) {
+  FTR_REQUIRE(B >= 0 && T >= 0 && S1 >= 0 && C >= 0, "normalizer_gemm: bad sizes");
+  if ((size_t)B * T * S1 * C == 0) return FTR_OK;
+  FTR_REQUIRE(x && y && out, "normalizer_gemm: null pointer");
+  return normalizer_gemm(kind, x, y, out, B, T, S1, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_normalizer_gemm_choice(int kind, int B, int T, int S1, int C, int* solution, float* us, float* us_default, int* candidates) {
+  return normalizer_gemm_choice(kind, B, T, S1, C, solution, us, us_default, candidates);
+}
+
+int ftr_normalizer_gemm_set_choice(int kind, int B, int T, int S1, int C, int solution) {
+  return normalizer_gemm_set_choice(kind, B, T, S1, C, solution);
+}
 
 int ftr_simple_logprobs_fused_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* am_probs,
                                       const float* lm_probs, const float* am_max, const float* lm_max,

@@ -142,6 +142,9 @@ int simple_logprobs_bwd_am(const float* gpx, const float* gpy, Scale scale, cons
 int simple_logprobs_bwd_lm(const float* dlmp, const float* lm_probs, const int32_t* symbols, const float* rsx, const float* rsy, int blank, float kdir, const float* arow, const float* invsum, const float* gu, float* d_lm, int B, int S, int C, hipStream_t st);
 int simple_fused_supported(int C);
 int simple_fused_bwd_supported(int T, int C);
+int normalizer_gemm(int kind, const float* x, const float* y, float* out, int B, int T, int S1, int C, hipStream_t st);
+int normalizer_gemm_choice(int kind, int B, int T, int S1, int C, int* solution, float* us, float* us_default, int* candidates);
+int normalizer_gemm_set_choice(int kind, int B, int T, int S1, int C, int solution);
 int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, const float* am_probs, const float* lm_probs, const float* am_max, const float* lm_max, const int32_t* boundary, int blank, double delay_penalty, const float* lmonly_norm, const float* amonly_norm, const float* ulog, float cs, float ls, float as, float* px, float* py, float* prod_out, int B, int T, int S, int C, int modified, hipStream_t st);
 int simple_fused_bwd_am(const float* gpx, const float* gpy, Scale scale, const float* prod, const float* lm_probs, const float* am_probs, const int32_t* symbols, const int32_t* boundary, int blank, float cs, float kdir, const float* uvec, const float* amdot, float as, float* Rout, float* d_am, int B, int T, int S, int C, int modified, hipStream_t st);
 int negated_reduce(const float* ans, int B, int reduction, float* out, hipStream_t st);

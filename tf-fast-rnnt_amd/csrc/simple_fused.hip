@@ -250,7 +250,7 @@ constexpr int kBLT = kBT + 4;                     // W tile row stride (floats)
 constexpr int kBCB = 16;                          // column blocks per workgroup (256 columns)
 
 __host__ __device__ constexpr size_t fused_bwd_lds_bytes() {
-  return sizeof(float) * (2 * kBS * (16 * kBCB) + 2 * kBS * kBLT + 2 * kBS * kBT) + sizeof(int) * 2 * kBS;
+  return sizeof(float) * (2 * kBS * (16 * kBCB) + 2 * kBS * kBLT + 2 * kBS * kBT);
 }
 
 template <bool MOD>
@@ -266,7 +266,6 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
   float* lmT = smem;                               // [2][kBS][LDC]   lm_probs rows of the chunk
   float* wT = lmT + 2 * kBS * LDC;                 // [2][kBS][kBLT]  W (pass 1) / kdir * gx (pass 2) rows of the chunk
   float* csb = wT + 2 * kBS * kBLT;                // [2][kBS][kBT]   partial column sums (x, y) per staging row class
-  int* symL = reinterpret_cast<int*>(csb + 2 * kBS * kBT);   // [2][kBS]
   // XCD-aware tile order (as in the forward kernel): workgroups are dealt to the eight XCDs round robin by linear id and
   // every XCD has its own L2; in launch order the tiles that share one utterance's lm_probs rows and one frame tile's
   // g_px / g_py / prod columns land on eight different L2s.  Here XCD k works through a contiguous eighth of the tile list.

@@ -15,7 +15,7 @@ from .rnnt_loss import rnnt_loss
 from .rnnt_loss import rnnt_loss_pruned
 from .rnnt_loss import rnnt_loss_simple
 from .rnnt_loss import rnnt_loss_smoothed
-from .rnnt_loss import tune_normalizer_gemms                # MI355X addition: library-GEMM kernel selection, see its docstring
+from .rnnt_loss import tune_normalizer_gemms, normalizer_gemm_choice, set_normalizer_gemm_choice                # MI355X addition: library-GEMM kernel selection, see its docstring
 
 __version__ = '1.2'
 

@@ -60,6 +60,9 @@ _SIGNATURES = {
     "ftr_colsum_weighted_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_size_t, ctypes.c_longlong, _i, _c_st]),
     "ftr_simple_logprobs_fused_supported": (_i, [_i]),
     "ftr_simple_logprobs_fused_bwd_supported": (_i, [_i, _i]),
+    "ftr_normalizer_gemm_f32": (_i, [_i, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
+    "ftr_normalizer_gemm_set_choice": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ftr_normalizer_gemm_choice": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
     "ftr_simple_logprobs_fused_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_fused_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, ctypes.c_double, _f, _f, _f, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_fused_bwd_am_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),

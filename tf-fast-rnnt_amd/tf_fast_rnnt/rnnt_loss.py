@@ -7,7 +7,7 @@ What runs where:
   ``do_rnnt_pruning``, ``get_rnnt_logprobs_pruned`` / ``rnnt_loss_pruned``: hand-written HIP behind the
   C ABI (include/ftr.h);
 * ``get_rnnt_logprobs`` / ``rnnt_loss_simple``: hand-written HIP prologue, epilogue and backward kernels around
-  the normaliser GEMM (rocBLAS through torch.bmm);
+  the normaliser GEMM (rocBLAS behind ftr_normalizer_gemm_f32);
 * ``get_rnnt_logprobs_smoothed`` / ``rnnt_loss_smoothed``: the same native kernels with the LM-only / AM-only
   terms folded in; only the [C]- and [rows]-sized batch statistics (unigram mean, two matvecs) are torch ops;
 * ``get_rnnt_logprobs_joint`` / ``rnnt_loss`` (unpruned, joiner logits [B,T,S+1,C]): the pruned builder's kernels
@@ -34,21 +34,46 @@ _NEG_INF = float("-inf")
 _TINY = 1.401298464324817e-45
 
 
-def tune_normalizer_gemms(enable: bool = True, filename: Optional[str] = None, search: bool = True) -> None:
+def tune_normalizer_gemms(enable: bool = True, filename: Optional[str] = None, search: bool = True, when: str = "second") -> None:
     """The dense contractions of the simple / smoothed builders that stay library f32 GEMMs (the two transposes of the
-    normaliser product in the backward; also the forward one when C % 4 != 0, rnnt_loss.py:180-182) run at 62-77 TFLOP/s
-    with rocBLAS' default kernel choice for these shapes on MI355X; letting the library time its candidate kernels once
-    per shape (PyTorch's TunableOp over rocBLAS / hipBLASLt) gives ~100 TFLOP/s (104/90/84 -> 65/62/60 us at B=32 T=1000
-    S=200 C=500).  Process-wide switch (it affects every torch GEMM of the process); with ``search`` the first call of
-    each new shape is slow and must not happen inside a stream capture.  ``filename``: where the choices are stored and
-    reloaded from; ``search=False`` only applies the choices already in that file."""
-    import torch.cuda.tunable as tunable
-    tunable.enable(bool(enable))
-    tunable.tuning_enable(bool(enable) and bool(search))
-    if filename is not None:
-        tunable.set_filename(filename)
-        if enable and os.path.exists(filename):
-            tunable.read_file(filename)
+    normaliser product in the backward; also the forward one when C % 4 != 0, rnnt_loss.py:180-182) go through
+    ``ftr_normalizer_gemm_f32`` (csrc/normalizer_gemm.hip): rocBLAS with the kernel chosen by MEASUREMENT -- rocBLAS' own
+    choice for these shapes runs at 62-77 TFLOP/s on MI355X, its best candidate at ~100 (104/90/84 -> 65/62/60 us at B=32
+    T=1000 S=200 C=500).  By default the library times the candidates at the second call with a shape (~0.2 s, never inside
+    a stream capture), so a loop with fixed shapes gets the fast kernel from its second step on without calling anything
+    and a ragged loop is never held up.  This function only moves that switch (the environment variable FTR_GEMM_TUNE):
+    ``enable=False`` or ``search=False`` -> "off" (shapes already measured keep their kernel), ``when`` = "first" | "second".
+    ``filename`` is accepted for compatibility and ignored (the choices live in the process; see
+    ``normalizer_gemm_choice`` / ``set_normalizer_gemm_choice`` to carry one over)."""
+    if when not in ("first", "second"):
+        raise ValueError("when must be 'first' or 'second'")
+    os.environ["FTR_GEMM_TUNE"] = when if (enable and search) else "off"
+
+
+def normalizer_gemm_choice(kind: int, B: int, T: int, S: int, C: int):
+    """What the library chose for the GEMM ``kind`` (0 forward product, 1 towards lm, 2 towards am) of this shape on the
+    current device: None if the shape has not run, else dict(solution, us, us_default, candidates) -- solution 0 is
+    rocBLAS' own choice, candidates -1 means not measured yet."""
+    import ctypes
+    sol, cand = ctypes.c_int(0), ctypes.c_int(0)
+    us, usd = ctypes.c_float(0), ctypes.c_float(0)
+    if not _lib.lib().ftr_normalizer_gemm_choice(int(kind), int(B), int(T), int(S) + 1, int(C), ctypes.byref(sol), ctypes.byref(us),
+                                                  ctypes.byref(usd), ctypes.byref(cand)):
+        return None
+    return dict(solution=sol.value, us=us.value, us_default=usd.value, candidates=cand.value)
+
+
+def set_normalizer_gemm_choice(kind: int, B: int, T: int, S: int, C: int, solution: int) -> None:
+    """Fixes the rocBLAS solution index for a shape without measuring (a choice recorded by an earlier process)."""
+    _lib.call("ftr_normalizer_gemm_set_choice", int(kind), int(B), int(T), int(S) + 1, int(C), int(solution))
+
+
+def _gemm(kind: int, x: torch.Tensor, y: torch.Tensor, B: int, T: int, S: int, C: int, st) -> torch.Tensor:
+    """ftr_normalizer_gemm_f32: kind 0 lm_probs . am_probs^T -> [B,S+1,T]; 1 W . am_probs -> [B,S+1,C]; 2 W^T . lm_probs -> [B,T,C]."""
+    shape = ((B, S + 1, T), (B, S + 1, C), (B, T, C))[kind]
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _lib.call("ftr_normalizer_gemm_f32", kind, _ptr(x), _ptr(y), _ptr(out), B, T, S + 1, C, st)
+    return out
 
 
 def _check_type(rnnt_type: str) -> None:
@@ -97,7 +122,7 @@ def _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, bound
                   _ptr(am_max), _ptr(lm_max), _ptr(boundary), int(blank), float(delay_penalty), _ptr(px), _ptr(py),
                   _ptr(prod), B, T, S, C, int(modified), st)
         return prod
-    prod = torch.bmm(lm_probs, am_probs.transpose(1, 2))                                             # :180-182
+    prod = _gemm(0, lm_probs, am_probs, B, T, S, C, st)                                               # :180-182
     _lib.call("ftr_simple_logprobs_fwd_f32", _ptr(amc), _ptr(lmc), _ptr(symbols), _ptr(prod), _ptr(am_max),
               _ptr(lm_max), _ptr(boundary), int(blank), float(delay_penalty), _ptr(px), _ptr(py),
               B, T, S, C, int(modified), st)
@@ -106,7 +131,7 @@ def _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, bound
 
 class _SimpleLogprobs(torch.autograd.Function):
     """get_rnnt_logprobs (+ fix_for_boundary + delay penalty) for regular/modified: native prologue and
-    epilogue kernels around the normaliser GEMM (torch.bmm -> rocBLAS), hand-written backward."""
+    epilogue kernels around the normaliser GEMM (ftr_normalizer_gemm_f32 -> rocBLAS), hand-written backward."""
 
     @staticmethod
     def forward(ctx, lm, am, symbols, termination_symbol, boundary, modified, delay_penalty):
@@ -149,13 +174,13 @@ class _SimpleLogprobs(torch.autograd.Function):
             st = _stream_ptr(am_probs)
             _lib.call("ftr_simple_logprobs_bwd_w_f32", _ptr(gpx), _ptr(gpy), _ptr(prod), _ptr(boundary), _ptr(W),
                       _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
-            dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+            dlmp = _gemm(1, W, am_probs, B, T, S, C, st)         # [B,S+1,C]
             if _use_fused_builder_bwd(T, C):                       # W^T lm_probs inside the d am kernel (opt-in)
                 _lib.call("ftr_simple_logprobs_fused_bwd_am_f32", _ptr(gpx), _ptr(gpy), None, 0, 1.0, _ptr(prod),
                           _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
                           modified, st)
             else:
-                damp = torch.bmm(W.transpose(1, 2), lm_probs)   # [B,T,C]
+                damp = _gemm(2, W, lm_probs, B, T, S, C, st)    # [B,T,C]
                 _lib.call("ftr_simple_logprobs_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(damp), _ptr(am_probs),
                           _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C, modified, st)
             _lib.call("ftr_simple_logprobs_bwd_lm_f32", _ptr(dlmp), _ptr(lm_probs), _ptr(symbols), _ptr(rsx), _ptr(rsy),
@@ -223,13 +248,13 @@ class _SimpleLoss(torch.autograd.Function):
             st = _stream_ptr(am_probs)
             _lib.call("ftr_simple_logprobs_bwd_w_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
                       _ptr(prod), _ptr(boundary), _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
-            dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+            dlmp = _gemm(1, W, am_probs, B, T, S, C, st)         # [B,S+1,C]
             if _use_fused_builder_bwd(T, C):                       # W^T lm_probs inside the d am kernel (opt-in)
                 _lib.call("ftr_simple_logprobs_fused_bwd_am_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
                           _ptr(prod), _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am),
                           B, T, S, C, modified, st)
             else:
-                damp = torch.bmm(W.transpose(1, 2), lm_probs)   # [B,T,C]
+                damp = _gemm(2, W, lm_probs, B, T, S, C, st)    # [B,T,C]
                 _lib.call("ftr_simple_logprobs_bwd_am_scaled_f32", _ptr(px_grad), _ptr(py_grad), _ptr(scale), stride, mul,
                           _ptr(damp), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, _ptr(d_am), B, T, S, C,
                           modified, st)
@@ -809,7 +834,7 @@ def _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, l
         _lib.call("ftr_rowmax_exp_dot_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), _ptr(u), _ptr(am_dot), B * T, C, st)
         fused = _use_fused_builder(C)
         prod = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev) if fused else \
-            torch.bmm(lm_probs, am_probs.transpose(1, 2))                                               # :1270-1272
+            _gemm(0, lm_probs, am_probs, B, T, S, C, st)                                                # :1270-1272
         amonly = (am_dot.log().reshape(B, T) + am_max).contiguous()                                     # :1281-1286
         ulog = u.log().contiguous()                                                                     # :1287
         lmonly = (lm_sum.log() + lm_max).contiguous()                                                   # :1288-1290
@@ -847,13 +872,13 @@ def _smoothed_backward(saved, has_boundary, meta, gpx, gpy, scale=None, stride=0
         st = _stream_ptr(am_probs)
         _lib.call("ftr_smoothed_logprobs_bwd_w_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
                   _ptr(boundary), cs, _ptr(W), _ptr(rsx), _ptr(rsy), B, T, S, modified, st)
-        dlmp = torch.bmm(W, am_probs)                       # [B,S+1,C]
+        dlmp = _gemm(1, W, am_probs, B, T, S, C, st)         # [B,S+1,C]
         if _use_fused_builder_bwd(T, C):                       # W^T lm_probs inside the d am kernel (opt-in)
             _lib.call("ftr_smoothed_logprobs_fused_bwd_am_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(prod),
                       _ptr(lm_probs), _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs, cs + a_s, _ptr(u),
                       _ptr(am_dot), a_s, _ptr(R), _ptr(d_am), B, T, S, C, modified, st)
         else:
-            damp = torch.bmm(W.transpose(1, 2), lm_probs)   # [B,T,C]
+            damp = _gemm(2, W, lm_probs, B, T, S, C, st)    # [B,T,C]
             _lib.call("ftr_smoothed_logprobs_bwd_am_scaled_f32", _ptr(gpx), _ptr(gpy), _ptr(scale), stride, mul, _ptr(damp),
                       _ptr(am_probs), _ptr(symbols), _ptr(boundary), blank, cs + a_s, _ptr(u), _ptr(am_dot), a_s, _ptr(R),
                       _ptr(d_am), B, T, S, C, modified, st)
