@@ -15,21 +15,33 @@
 // MFMA operand roles: A = am_probs tile (M = frames), B = lm_probs tile (N = symbol rows), so that an accumulator
 // register quad holds four CONSECUTIVE FRAMES of one symbol row: px / py / prod rows are written 16 bytes per lane.
 #include "ftr_common.h"
+#include <cstdlib>
 
 namespace ftr {
 namespace {
 
 constexpr float kTinyF = 1.401298464324817e-45f;  // tf.math.nextafter(0., 1.)  (rnnt_loss.py:181)
-constexpr int kFT = 64;                           // frames per workgroup: 4 waves x one 16-frame MFMA block
-constexpr int kFK = 32;                           // columns of C staged per step
-constexpr int kFLD = kFK + 4;                     // LDS row stride (floats): 16-byte aligned, b128 fragment reads conflict free
+// frames per workgroup: 64 MB -- 4 waves x MB 16-frame MFMA blocks (wave w owns frames 16 w + 64 m .. + 15, m < MB);
+// 32 columns of C staged per step (128 contiguous bytes of every tile row); LDS row stride = that + 4 floats (16-byte aligned,
+// b128 fragment reads conflict free).  MB = 1 double-buffers the tile in LDS (one barrier per step); MB = 2 keeps ONE buffer
+// (the tile of 128 + 16 NS rows would not leave room for two workgroups per CU otherwise: 83 KB at NS = 10) and pays a second
+// barrier per step, against 16 NS MFMAs per wave and step.  MB = 2 re-reads an utterance's lm_probs rows half as often and
+// feeds two MFMAs from every B fragment: it is taken where those rows do not stay in an XCD's L2 anyway (see the launcher).
+template <int MB> struct FusedTile {
+  static constexpr int FT = 64 * MB, FK = 32, FLD = FK + 4, NBUF = MB == 1 ? 2 : 1;
+};
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int NS>
-__host__ __device__ constexpr size_t fused_lds_bytes() { return sizeof(float) * 2 * (size_t)(kFT + 16 * NS) * kFLD; }
+constexpr int kGLD = 68;   // row stride (floats) of the epilogue's gather buffer: 64 frames + 4, rows stay 16-byte aligned
+template <int NS, int MB>
+__host__ __device__ constexpr size_t fused_lds_bytes() {
+  constexpr size_t tile = FusedTile<MB>::NBUF * (size_t)(FusedTile<MB>::FT + 16 * NS) * FusedTile<MB>::FLD;
+  constexpr size_t gather = (size_t)16 * NS * kGLD + 16 * NS;   // am[t, sym(s)] of 64 frames x 16 NS rows + the symbols (epilogue)
+  return sizeof(float) * (tile > gather ? tile : gather);
+}
 
-// grid (ceil(T1 / 64), ceil((S+1) / (16 NS)), B), 256 threads.
-template <bool MOD, bool SMOOTH, int NS>
+// grid (ceil(T1 / (64 MB)), ceil((S+1) / (16 NS)), B), 256 threads.
+template <bool MOD, bool SMOOTH, int NS, int MB>
 __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
     const float* __restrict__ am, const float* __restrict__ lm, const int32_t* __restrict__ symbols,
     const float* __restrict__ am_probs, const float* __restrict__ lm_probs, const float* __restrict__ am_max,
@@ -37,9 +49,11 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
     const float* __restrict__ lmonly_norm, const float* __restrict__ amonly_norm, const float* __restrict__ ulog,
     float cs, float ls, float as, float* __restrict__ px, float* __restrict__ py, float* __restrict__ prod_out, int T,
     int S, int C) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][ROWS][kFLD]: rows 0..63 frames, then 16 NS symbol rows
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NBUF][ROWS][kFLD]: rows 0..FT-1 frames, then 16 NS symbol rows
+  constexpr int kFT = FusedTile<MB>::FT, kFK = FusedTile<MB>::FK, kFLD = FusedTile<MB>::FLD, NBUF = FusedTile<MB>::NBUF;
+  constexpr int PPR = kFK / 4;                     // 16-byte pieces per tile row and chunk
   constexpr int ROWS = kFT + 16 * NS;
-  constexpr int NU = (ROWS * 8 + 255) / 256;      // 16-byte pieces per thread and chunk
+  constexpr int NU = (ROWS * PPR + 255) / 256;    // 16-byte pieces per thread and chunk
   // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and every XCD has its own L2: in
   // launch order the frame tiles that share one utterance's lm_probs rows (416 KB at c3) are spread over all eight, and each
   // L2 fetches them again (PMC: 327 MB fetched for 77 MB of operands).  Here XCD k works through a contiguous eighth of the
@@ -63,13 +77,13 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
   const float* amp = am_probs + (size_t)b * T * C;
   const float* lmp = lm_probs + (size_t)b * (S + 1) * C;
 
-  // ---- staging plan: piece e = tid + 256 u is 4 columns (e & 7) of tile row (e >> 3)
+  // ---- staging plan: piece e = tid + 256 u is 4 columns (e % PPR) of tile row (e / PPR)
   const float* src[NU];
   bool live[NU];
   int dst[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int e = tid + 256 * u, row = e >> 3, c4 = e & 7;
+    const int e = tid + 256 * u, row = e / PPR, c4 = e % PPR;
     live[u] = false; src[u] = amp; dst[u] = row * kFLD + 4 * c4;
     if (row < kFT) { const int t = t0 + row; if (t < T) { live[u] = true; src[u] = amp + (size_t)t * C + 4 * c4; } }
     else if (row < ROWS) { const int s = s0 + row - kFT; if (s <= S) { live[u] = true; src[u] = lmp + (size_t)s * C + 4 * c4; } }
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
   auto gload = [&](int kc, f4 (&v)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int k = kc * kFK + 4 * ((tid + 256 * u) & 7);
+      const int k = kc * kFK + 4 * ((tid + 256 * u) % PPR);
       v[u] = f4{0.f, 0.f, 0.f, 0.f};
       if (live[u] && k < C) v[u] = *reinterpret_cast<const f4*>(src[u] + kc * kFK);   // C % 4 == 0: k < C covers k + 3
     }
@@ -85,34 +99,39 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
   auto lstore = [&](int buf, const f4 (&v)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-      if (tid + 256 * u < ROWS * 8) *reinterpret_cast<f4*>(smem + buf * ROWS * kFLD + dst[u]) = v[u];
+      if (tid + 256 * u < ROWS * PPR) *reinterpret_cast<f4*>(smem + buf * ROWS * kFLD + dst[u]) = v[u];
   };
 
-  v4f acc[NS];
+  v4f acc[MB][NS];
 #pragma unroll
-  for (int i = 0; i < NS; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[m][i] = v4f{0.f, 0.f, 0.f, 0.f};
   const int nk = (C + kFK - 1) / kFK;
   f4 v[NU];
   gload(0, v);
   lstore(0, v);
   __syncthreads();
   const int frag = (lane & 15) * kFLD + 4 * (lane >> 4);   // this lane's row and its 4 of every 16 columns
-#if defined(FTR_FUSED_EXP) && FTR_FUSED_EXP == 2   // diagnostic: no contraction
+#if defined(FTR_FUSED_EXP) && FTR_FUSED_EXP >= 2   // diagnostic: no contraction
   for (int kc = 0; kc < 0; ++kc) {
 #else
   for (int kc = 0; kc < nk; ++kc) {
 #endif
     if (kc + 1 < nk) gload(kc + 1, v);
-    const float* A = smem + (kc & 1) * ROWS * kFLD + 16 * wave * kFLD + frag;
-    const float* Bm = smem + (kc & 1) * ROWS * kFLD + kFT * kFLD + frag;
+    const int cur = NBUF == 2 ? (kc & 1) : 0;
+    const float* A = smem + cur * ROWS * kFLD + 16 * wave * kFLD + frag;
+    const float* Bm = smem + cur * ROWS * kFLD + kFT * kFLD + frag;
     // One unit = the four MFMAs of (column group g, symbol block i): 2 NS units per chunk, taken in pairs that alternate
     // between two accumulators; the B fragments run through a small register ring fetched kAheadU units ahead of their
     // use (fetching a whole chunk's fragments up front makes the compiler recycle registers and wait on every reuse).
     constexpr int NUNIT = (kFK / 16) * NS;
     constexpr int kAheadU = 4, RING = 8;
-    f4 af[kFK / 16], ring[RING];
+    f4 af[MB][kFK / 16], ring[RING];
 #pragma unroll
-    for (int g = 0; g < kFK / 16; ++g) af[g] = *reinterpret_cast<const f4*>(A + 16 * g);
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int g = 0; g < kFK / 16; ++g) af[m][g] = *reinterpret_cast<const f4*>(A + 64 * m * kFLD + 16 * g);
     auto bfetch = [&](int u) { return *reinterpret_cast<const f4*>(Bm + (u % NS) * 16 * kFLD + 16 * (u / NS)); };
 #pragma unroll
     for (int u = 0; u < kAheadU; ++u) if (u < NUNIT) ring[u % RING] = bfetch(u);
@@ -127,42 +146,38 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
         const f4 b1 = ring[(u + 1) % RING];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[i0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g0][e], b0[e], acc[i0], 0, 0, 0);
-          acc[i1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g1][e], b1[e], acc[i1], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            acc[m][i0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][g0][e], b0[e], acc[m][i0], 0, 0, 0);
+            acc[m][i1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][g1][e], b1[e], acc[m][i1], 0, 0, 0);
+          }
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g0][e], b0[e], acc[i0], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int m = 0; m < MB; ++m) acc[m][i0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][g0][e], b0[e], acc[m][i0], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the fetch-ahead order: the scheduler otherwise regroups the units and waits on fresh reads
     }
-    if (kc + 1 < nk) lstore((kc + 1) & 1, v);
+    if (NBUF == 1) __syncthreads();   // one buffer: every wave has read its fragments before the next chunk overwrites them
+    if (kc + 1 < nk) lstore(NBUF == 2 ? ((kc + 1) & 1) : 0, v);
     __syncthreads();
   }
 
 #if defined(FTR_FUSED_EXP) && FTR_FUSED_EXP == 1   // diagnostic: no epilogue (accumulators summed into one store)
-  { float t = 0.f; for (int i = 0; i < NS; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; if (t == 123.456f) py[0] = t; return; }
+  { float t = 0.f; for (int m = 0; m < MB; ++m) for (int i = 0; i < NS; ++i) t += acc[m][i][0] + acc[m][i][1] + acc[m][i][2] + acc[m][i][3]; if (t == 123.456f) py[0] = t; return; }
 #endif
-  // ---- epilogue: lane (n = lane & 15, q = lane >> 4) holds, per symbol block i, frames tq .. tq+3 of row s0 + 16 i + n
+  // ---- epilogue: lane (n = lane & 15, q = lane >> 4) holds, per frame block m and symbol block i, frames tq .. tq+3 of row
+  // s0 + 16 i + n, tq = t0 + 64 m + 16 wave + 4 q
   const int n = lane & 15;
-  const int tq = t0 + 16 * wave + 4 * (lane >> 4);
-  if (tq >= T1) return;
   const int te = boundary ? boundary[4 * b + 3] : T;
   const float* amb = am + (size_t)b * T * C;
   const float* lmb = lm + (size_t)b * (S + 1) * C;
-  float amx[4], a_blank[4], aon[4], pen[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t = tq + j;
-    const bool in = t < T;
-    amx[j] = in ? am_max[(size_t)b * T + t] : 0.0f;
-    a_blank[j] = in ? amb[(size_t)t * C + blank] : 0.0f;
-    aon[j] = (SMOOTH && in) ? amonly_norm[(size_t)b * T + t] : 0.0f;
-    pen[j] = (delay_penalty > 0.0) ? (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty) : 0.0f;   // :305-321
-  }
   const float ulog_blank = SMOOTH ? ulog[blank] : 0.0f;
-  // The epilogue's loads are issued in three independent batches (row scalars; lm at the symbol; the 4 x NS am gathers)
-  // so that they are all in flight together: taken block by block they form NS serial chains of three dependent loads.
+  // The epilogue's loads are issued in independent batches (row scalars; lm at the symbol; per frame block the frame scalars
+  // and the 4 x NS am gathers) so that they are all in flight together: taken block by block they form NS serial chains of
+  // three dependent loads.
   int sym[NS];
   float lm_blank[NS], lmx[NS], lon[NS], lm_sym[NS], ulog_sym[NS];
 #pragma unroll
@@ -179,45 +194,91 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
     lm_sym[i] = lmb[(size_t)s * C + sym[i]];
     ulog_sym[i] = SMOOTH ? ulog[sym[i]] : 0.0f;
   }
-  float a_sym[NS][4];
+  // am[t, sym(s)] for the 64 x 16 NS cells of a frame block: taken lane by lane in accumulator layout these are 4 NS gathers
+  // per lane whose 64 addresses per instruction lie in 64 different lines (4 frames x 16 symbols) -- 105 of the kernel's 540 us
+  // at c4, 23 of 105 at c3 (scripts/fused_split.sh).  Instead the workgroup gathers FRAME by FRAME into the tile's LDS (free
+  // now): one instruction covers 64 symbols of ONE am row (<= 32 lines, the next instruction of the frame hits the same ones),
+  // every line of the am tile comes from L2 once, and each lane then reads its four consecutive frames with one ds_read_b128.
+  float* asym = smem;                                             // [16 NS][kGLD]
+  int* sym_l = reinterpret_cast<int*>(smem + 16 * NS * kGLD);     // [16 NS]
+  if (wave == 0 && (lane >> 4) == 0) {
 #pragma unroll
-  for (int i = 0; i < NS; ++i)
+    for (int i = 0; i < NS; ++i) sym_l[16 * i + n] = sym[i];
+  }
+  __syncthreads();
+  constexpr int NSL = (16 * NS + 63) / 64;
+  int mysym[NSL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a_sym[i][j] = amb[(size_t)min(tq + j, T - 1) * C + sym[i]];
+  for (int u = 0; u < NSL; ++u) mysym[u] = sym_l[min(lane + 64 * u, 16 * NS - 1)];
 #pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int s = s0 + 16 * i + n;
-    if (s > S) continue;
-    f4 vy, vx, vp;
+  for (int m = 0; m < MB; ++m) {
+    if (m > 0) __syncthreads();                                   // the previous block's values have been read
+#if !(defined(FTR_FUSED_EXP) && (FTR_FUSED_EXP == 3 || FTR_FUSED_EXP == 5))
+#pragma unroll 4
+    for (int f = wave; f < 64; f += 4) {                          // 16 frames per wave, NSL gathers each
+      const float* row = amb + (size_t)min(t0 + 64 * m + f, T - 1) * C;
+#pragma unroll
+      for (int u = 0; u < NSL; ++u) {
+        const int sl = lane + 64 * u;
+        const float v = row[mysym[u]];
+        if (sl < 16 * NS) asym[sl * kGLD + f] = v;
+      }
+    }
+#endif
+    __syncthreads();
+    const int tq = t0 + 64 * m + 16 * wave + 4 * (lane >> 4);
+    if (tq >= T1) continue;                                       // (no barrier below this point inside the block)
+    float amx[4], a_blank[4], aon[4], pen[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = tq + j;
-      const float pr = acc[i][j];
-      vp[j] = pr;
-      const float nrm = logf(pr + kTinyF) + lmx[i] + amx[j];                                                    // :180-186
-      float y = a_blank[j] + lm_blank[i] - nrm;                                                                 // :214-216
-      if (SMOOTH) y = y * cs + (lm_blank[i] - lon[i]) * ls + (a_blank[j] + ulog_blank - aon[j]) * as;           // :1333-1360
-      vy[j] = y;
-      float x = -INFINITY;                                                  // px[:, :, T] (:193-203), fix_for_boundary (:218-219)
-      if (s < S && t < T && (MOD || t != te)) {
-        x = a_sym[i][j] + lm_sym[i] - nrm;                                                                      // :187-211
-        if (SMOOTH) x = x * cs + (lm_sym[i] - lon[i]) * ls + (a_sym[i][j] + ulog_sym[i] - aon[j]) * as;         // :1323-1355
+      const bool in = t < T;
+      amx[j] = in ? am_max[(size_t)b * T + t] : 0.0f;
+      a_blank[j] = in ? amb[(size_t)t * C + blank] : 0.0f;
+      aon[j] = (SMOOTH && in) ? amonly_norm[(size_t)b * T + t] : 0.0f;
+      pen[j] = (delay_penalty > 0.0) ? (float)((((double)te - 1.0) / 2.0 - (double)t) * delay_penalty) : 0.0f;   // :305-321
+    }
+    f4 a_sym[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) a_sym[i] = *reinterpret_cast<const f4*>(asym + (16 * i + n) * kGLD + 16 * wave + 4 * (lane >> 4));
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int s = s0 + 16 * i + n;
+      if (s > S) continue;
+      f4 vy, vx, vp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = tq + j;
+        const float pr = acc[m][i][j];
+        vp[j] = pr;
+        const float nrm = logf(pr + kTinyF) + lmx[i] + amx[j];                                                    // :180-186
+        float y = a_blank[j] + lm_blank[i] - nrm;                                                                 // :214-216
+        if (SMOOTH) y = y * cs + (lm_blank[i] - lon[i]) * ls + (a_blank[j] + ulog_blank - aon[j]) * as;           // :1333-1360
+        vy[j] = y;
+        float x = -INFINITY;                                                  // px[:, :, T] (:193-203), fix_for_boundary (:218-219)
+        if (s < S && t < T && (MOD || t != te)) {
+          x = a_sym[i][j] + lm_sym[i] - nrm;                                                                      // :187-211
+          if (SMOOTH) x = x * cs + (lm_sym[i] - lon[i]) * ls + (a_sym[i][j] + ulog_sym[i] - aon[j]) * as;         // :1323-1355
+        }
+        if (delay_penalty > 0.0) x += pen[j];
+        vx[j] = x;
       }
-      if (delay_penalty > 0.0) x += pen[j];
-      vx[j] = x;
-    }
-    float* yrow = py + ((size_t)b * (S + 1) + s) * T + tq;
-    if (tq + 3 < T) *reinterpret_cast<f4u*>(yrow) = vy;
-    else { for (int j = 0; j < 4; ++j) if (tq + j < T) yrow[j] = vy[j]; }
-    if (prod_out) {
-      float* prow = prod_out + ((size_t)b * (S + 1) + s) * T + tq;
-      if (tq + 3 < T) *reinterpret_cast<f4u*>(prow) = vp;
-      else { for (int j = 0; j < 4; ++j) if (tq + j < T) prow[j] = vp[j]; }
-    }
-    if (s < S) {
-      float* xrow = px + ((size_t)b * S + s) * T1 + tq;
-      if (tq + 3 < T1) *reinterpret_cast<f4u*>(xrow) = vx;
-      else { for (int j = 0; j < 4; ++j) if (tq + j < T1) xrow[j] = vx[j]; }
+#if defined(FTR_FUSED_EXP) && (FTR_FUSED_EXP == 4 || FTR_FUSED_EXP == 5)    // diagnostic: one store per WG instead of all of them
+      if (vy[0] + vx[1] + vp[2] != 123.456f) continue;
+#endif
+      float* yrow = py + ((size_t)b * (S + 1) + s) * T + tq;
+      if (tq + 3 < T) *reinterpret_cast<f4u*>(yrow) = vy;
+      else { for (int j = 0; j < 4; ++j) if (tq + j < T) yrow[j] = vy[j]; }
+      if (prod_out) {
+        float* prow = prod_out + ((size_t)b * (S + 1) + s) * T + tq;
+        if (tq + 3 < T) *reinterpret_cast<f4u*>(prow) = vp;
+        else { for (int j = 0; j < 4; ++j) if (tq + j < T) prow[j] = vp[j]; }
+      }
+      if (s < S) {
+        float* xrow = px + ((size_t)b * S + s) * T1 + tq;
+        if (tq + 3 < T1) *reinterpret_cast<f4u*>(xrow) = vx;
+        else { for (int j = 0; j < 4; ++j) if (tq + j < T1) xrow[j] = vx[j]; }
+      }
     }
   }
 }
@@ -492,31 +553,39 @@ int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, c
   const int ny = (blocks + 12) / 13;
   const int need = (blocks + ny - 1) / ny;                     // symbol blocks per workgroup, <= 13
   const int ns = need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : 13;
-  const dim3 grid((T1 + kFT - 1) / kFT, (blocks + ns - 1) / ns, B);
+  // 128-frame tiles where one utterance's lm_probs rows of a tile (16 ns C floats) exceed what the XCD-aware order keeps in
+  // an L2 (> 512 KB: that order is off, every frame tile fetches the rows through the fabric) and there are frames for it;
+  // FTR_FUSED_FT = 64 | 128 forces one (A/B measurements)
+  int mb = ((size_t)16 * ns * C * sizeof(float) > 512 * 1024 && T1 > 64) ? 2 : 1;
+  if (const char* e = getenv("FTR_FUSED_FT")) { const int v = atoi(e); if (v == 64) mb = 1; else if (v == 128) mb = 2; }
+  const dim3 grid((T1 + 64 * mb - 1) / (64 * mb), (blocks + ns - 1) / ns, B);
   if (grid.z > 65535) { set_error("simple_logprobs_fused_fwd: B = %d > 65535", B); return FTR_ERR_UNSUPPORTED; }
   const bool smooth = lmonly_norm != nullptr;
-#define FTR_FUSED_LAUNCH(MODV, SMV, NSV)                                                                                   \
+#define FTR_FUSED_LAUNCH(MODV, SMV, NSV, MBV)                                                                              \
   do {                                                                                                                     \
     static bool raised = false;                                                                                            \
-    if (!raised && fused_lds_bytes<NSV>() > 64 * 1024) {                                                                   \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(simple_fused_fwd_kernel<MODV, SMV, NSV>),                       \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes<NSV>()) != hipSuccess) {    \
+    if (!raised && fused_lds_bytes<NSV, MBV>() > 64 * 1024) {                                                              \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(simple_fused_fwd_kernel<MODV, SMV, NSV, MBV>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes<NSV, MBV>()) != hipSuccess) { \
         (void)hipGetLastError(); set_error("simple_logprobs_fused_fwd: cannot raise the dynamic LDS limit"); return FTR_ERR_LAUNCH; \
       }                                                                                                                    \
       raised = true;                                                                                                       \
     }                                                                                                                      \
-    hipLaunchKernelGGL((simple_fused_fwd_kernel<MODV, SMV, NSV>), grid, dim3(256), fused_lds_bytes<NSV>(), st, am, lm,     \
-                       symbols, am_probs, lm_probs, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm,           \
+    hipLaunchKernelGGL((simple_fused_fwd_kernel<MODV, SMV, NSV, MBV>), grid, dim3(256), (fused_lds_bytes<NSV, MBV>()), st,   \
+                       am, lm, symbols, am_probs, lm_probs, am_max, lm_max, boundary, blank, delay_penalty, lmonly_norm,   \
                        amonly_norm, ulog, cs, ls, as, px, py, prod_out, T, S, C);                                         \
   } while (0)
+#define FTR_FUSED_MB(MODV, SMV, NSV)                                                                                       \
+  do { if (mb == 2) FTR_FUSED_LAUNCH(MODV, SMV, NSV, 2); else FTR_FUSED_LAUNCH(MODV, SMV, NSV, 1); } while (0)
 #define FTR_FUSED_NS(MODV, SMV)                                                                                            \
   do {                                                                                                                     \
-    if (ns == 4) FTR_FUSED_LAUNCH(MODV, SMV, 4); else if (ns == 7) FTR_FUSED_LAUNCH(MODV, SMV, 7);                          \
-    else if (ns == 10) FTR_FUSED_LAUNCH(MODV, SMV, 10); else FTR_FUSED_LAUNCH(MODV, SMV, 13);                               \
+    if (ns == 4) FTR_FUSED_MB(MODV, SMV, 4); else if (ns == 7) FTR_FUSED_MB(MODV, SMV, 7);                                  \
+    else if (ns == 10) FTR_FUSED_MB(MODV, SMV, 10); else FTR_FUSED_MB(MODV, SMV, 13);                                       \
   } while (0)
   if (modified) { if (smooth) FTR_FUSED_NS(true, true); else FTR_FUSED_NS(true, false); }
   else { if (smooth) FTR_FUSED_NS(false, true); else FTR_FUSED_NS(false, false); }
 #undef FTR_FUSED_NS
+#undef FTR_FUSED_MB
 #undef FTR_FUSED_LAUNCH
   return check_launch("simple_logprobs_fused_fwd");
 }
