@@ -13,6 +13,8 @@
 //   capi_host.bin pipeline <dir> B S T C r blank delay_penalty
 //   in : <dir>/am.bin lm.bin symbols.bin boundary.bin ranges.bin logits.bin
 //   out: builder_px.bin builder_py.bin         ftr_rowmax_exp_f32 x2 -> ftr_simple_logprobs_fused_fwd_f32  (when C % 4 == 0)
+//        simple_d_am.bin simple_d_lm.bin       ... -> recursion fwd + bwd -> ftr_simple_logprobs_bwd_w_scaled_f32 ->
+//                                              ftr_normalizer_gemm_f32 (1, 2) -> ..._bwd_am_scaled_f32, ..._bwd_lm_f32
 //        am_pruned.bin lm_pruned.bin           ftr_do_pruning_f32 with both output pointers (what tf.broadcast_to + tf.gather give)
 //        lm_pruned_only.bin                    ftr_do_pruning_f32 with am_pruned = NULL (the gather alone)
 //        pruned_ans.bin logits_grad.bin        ftr_pruned_band_fwd_f32 -> ftr_mutual_information_band_ws_f32 ->
@@ -83,6 +85,29 @@ static int pipeline_main(int argc, char** argv) {
     write_file(dir + "/builder_px.bin", px, npx);
     write_file(dir + "/builder_py.bin", py, npy);
     builder = 1;
+    // rnnt_loss_simple(reduction="sum") backward from here, as autodiff replays rnnt_loss.py:175-221: occupancies from the
+    // recursion, W, the two matmuls (ftr_normalizer_gemm_f32 kinds 1 and 2: rocBLAS behind the C ABI; called twice so that
+    // the second call measures the library's candidates), the two epilogues.  d loss / d ans = -1: scale = NULL, scale_mul = -1.
+    const size_t nws1 = ftr_mutual_information_workspace_floats(B, S, T);
+    float* ws1 = device_alloc<float>(nws1);
+    float* ans1 = device_alloc<float>(B); float* gx = device_alloc<float>(npx); float* gy = device_alloc<float>(npy);
+    FTR_CALL(ftr_mutual_information_fwd_ws_f32(px, py, bd, ws1, nws1, 0, ans1, B, S, T, 0, st));
+    FTR_CALL(ftr_mutual_information_bwd_ws_f32(px, py, bd, ws1, nws1, 0, nullptr, gx, gy, nullptr, 0, B, S, T, 0, st));
+    float* W = device_alloc<float>(npy); float* rsx = device_alloc<float>((size_t)B * (S + 1)); float* rsy = device_alloc<float>((size_t)B * (S + 1));
+    float* dlmp = device_alloc<float>(nlm); float* damp = device_alloc<float>(nam);
+    float* d_am = device_alloc<float>(nam); float* d_lm = device_alloc<float>(nlm);
+    FTR_CALL(ftr_simple_logprobs_bwd_w_scaled_f32(gx, gy, nullptr, 0, -1.0f, prod, bd, W, rsx, rsy, B, T, S, 0, st));
+    for (int rep = 0; rep < 2; ++rep) {
+      FTR_CALL(ftr_normalizer_gemm_f32(1, W, am_probs, dlmp, B, T, S + 1, C, st));
+      FTR_CALL(ftr_normalizer_gemm_f32(2, W, lm_probs, damp, B, T, S + 1, C, st));
+    }
+    int sol = -1, cand = -2;
+    if (!ftr_normalizer_gemm_choice(1, B, T, S + 1, C, &sol, nullptr, nullptr, &cand) || cand < 0) { fprintf(stderr, "GEMM kind 1 was not measured at its second call (candidates %d)\n", cand); return 10; }
+    FTR_CALL(ftr_simple_logprobs_bwd_am_scaled_f32(gx, gy, nullptr, 0, -1.0f, damp, am_probs, sym, bd, blank, d_am, B, T, S, C, 0, st));
+    FTR_CALL(ftr_simple_logprobs_bwd_lm_f32(dlmp, lm_probs, sym, rsx, rsy, blank, d_lm, B, S, C, st));
+    HIP_OK(hipStreamSynchronize(st));
+    write_file(dir + "/simple_d_am.bin", d_am, nam);
+    write_file(dir + "/simple_d_lm.bin", d_lm, nlm);
   }
 
   // do_rnnt_pruning (rnnt_loss.py:763-812): both outputs, then the gather alone

@@ -7,6 +7,7 @@ import subprocess
 
 import numpy as np
 import pytest
+import torch
 
 from helpers import max_rel
 
@@ -43,10 +44,11 @@ def test_cxx_host_runs_the_abi(dev, tmp_path, name, r):
 
 
 @pytest.mark.parametrize("name,r", [("c1_B2_T8_S4_C16", 3), ("seed1234_B2_T10_S7_C4", 3), ("seed12345_B2_T200_S50_C50", 5)])
-def test_cxx_host_runs_the_python_level_entry_points(dev, tmp_path, name, r):
+def test_cxx_host_runs_the_python_level_entry_points(ft, dev, tmp_path, name, r):
     """The entry points that replace the reference's Python functions, from the compiled host: the fused px / py builder
-    (when C % 4 == 0), do_rnnt_pruning in both output modes, and the band-native pruned loss with its gradient -- compared
-    with the golden fixture (builder px / py, pruned loss and gradient) and with numpy (the gather, bit-exact)."""
+    (when C % 4 == 0) and the simple loss's backward through the library-GEMM entry, do_rnnt_pruning in both output modes, and
+    the band-native pruned loss with its gradient -- compared with the golden fixture (builder px / py, pruned loss and
+    gradient), with the package's autograd node (d am, d lm) and with numpy (the gather, bit-exact)."""
     assert os.path.exists(HOST), "tests/capi_host/capi_host.bin is missing: run __graft_entry__.build()"
     g = np.load(os.path.join(HERE, "golden", name + ".npz"))
     am, lm, sym, bd = g["am"], g["lm"], g["symbols"].astype(np.int32), g["boundary"].astype(np.int32)
@@ -69,6 +71,13 @@ def test_cxx_host_runs_the_python_level_entry_points(dev, tmp_path, name, r):
         px, py = rd("builder_px", np.float32, g["simple_px"].shape), rd("builder_py", np.float32, g["simple_py"].shape)
         assert np.array_equal(np.isneginf(px), np.isneginf(g["simple_px"]))
         assert max_rel(px, g["simple_px"]) <= 1e-5 and max_rel(py, g["simple_py"]) <= 1e-5
+        # the simple loss's gradient w.r.t. am / lm driven from C++ (W -> ftr_normalizer_gemm_f32 x2 -> epilogues) against the
+        # package's own autograd node on the same inputs
+        lm_t = torch.from_numpy(g["lm"]).to(dev).requires_grad_(True); am_t = torch.from_numpy(g["am"]).to(dev).requires_grad_(True)
+        ft.rnnt_loss_simple(lm_t, am_t, torch.from_numpy(g["symbols"]).to(dev), blank, boundary=torch.from_numpy(g["boundary"]).to(dev),
+                            reduction="sum").backward()
+        assert max_rel(rd("simple_d_am", np.float32, g["am"].shape), am_t.grad.cpu().numpy()) <= 1e-5
+        assert max_rel(rd("simple_d_lm", np.float32, g["lm"].shape), lm_t.grad.cpu().numpy()) <= 1e-5
     else:
         assert "builder=0" in out.stdout
     assert np.array_equal(rd("am_pruned", np.float32, (B, T, r, C)), am_p)
