@@ -155,8 +155,8 @@ CALL_KERNELS = {
     "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
     "ftr_do_pruning_bwd_ws_f32": ["do_pruning_bwd_seg_kernel<5, true>", "do_pruning_bwd_reduce_kernel"],
-    "ftr_pruned_logprobs_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_to_lattice_kernel<false>"],
-    "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2, 2>", "band_gather_kernel<false>"],
+    "ftr_pruned_logprobs_fwd_f32": ["lse_rows_reg_kernel<2>", "band_to_lattice_kernel<false>"],
+    "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2>", "band_gather_kernel<false>"],
     "ftr_mutual_information_band_f32": ["mi_band_kernel<false, 8>"],
     "ftr_mutual_information_band_ws_f32": ["mi_band_kernel<false, 8>"],
     "ftr_pruned_band_bwd_scaled_f32": ["band_grad_banded_kernel<true>"],

@@ -14,64 +14,39 @@ namespace {
 __device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
-// logsumexp of each row, the row held in registers (C % 4 == 0, C <= 256 * NQ): one 16-byte load per lane and quad,
-// all of a wave's loads (RW rows x NQ quads) issued before the first is used, a single pass over the data.
-template <int NQ, int RW>
+// logsumexp of each row, the row held in registers (C % 4 == 0, C <= 256 * NQ): one wave per row, one 16-byte load per lane
+// and quad, all issued before the first is used, a single pass over the data, one short-lived wave per row and as many waves
+// as the chip holds.  (Rounds 1 - 2 ran this as 2048 persistent blocks, two rows per pass, the next pass's loads in flight
+// while one is reduced: 73 us at c3 = 4.4 TB/s; scripts/probes/stream_probe.hip measures the plain form below at 55 us =
+// 5.8 TB/s on the same tensor -- a flat read reaches 6.7 -- and 205 against 250 us at c4.  The memory system likes many short
+// waves better than few clever ones.)
+template <int NQ>
 __global__ __launch_bounds__(256) void lse_rows_reg_kernel(const float* __restrict__ logits, float* __restrict__ lse,
                                                            size_t rows, int C) {
-  // persistent waves: RW rows per pass, the next pass's rows are requested before this pass is reduced
   const int lane = threadIdx.x & 63;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
   const int n4 = C >> 2;
   const f4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  auto fetch = [&](size_t row0, f4 (&v)[RW][NQ]) {
+  const f4u* x4 = reinterpret_cast<const f4u*>(logits + row * C);
+  f4 v[NQ];
 #pragma unroll
-    for (int w = 0; w < RW; ++w) {
-      const size_t row = (row0 + w < rows) ? row0 + w : rows - 1;   // tail: recompute the last row, write guarded below
-      const f4u* x4 = reinterpret_cast<const f4u*>(logits + row * C);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int i = lane + 64 * q;
-        v[w][q] = (i < n4) ? (f4)x4[i] : ninf;
-      }
-    }
-  };
-  auto reduce = [&](size_t row0, const f4 (&v)[RW][NQ]) {
-#pragma unroll
-    for (int w = 0; w < RW; ++w) {
-      float m = -INFINITY;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(v[w][q][0], v[w][q][1])), fmaxf(v[w][q][2], v[w][q][3]));
-      m = wave_max(m);
-      float sum = 0.0f;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel
-          sum += __expf(v[w][q][0] - m) + __expf(v[w][q][1] - m) + __expf(v[w][q][2] - m) + __expf(v[w][q][3] - m);
-      }
-      sum = wave_sum(sum);
-      if (lane == 0 && row0 + w < rows) lse[row0 + w] = m + __logf(sum);
-    }
-  };
-  // two register sets used in turn (no copies): while one is reduced the other one's loads are in flight
-  const size_t stride = nwaves * RW;
-  size_t row0 = wave * RW;
-  if (row0 >= rows) return;
-  f4 bufa[RW][NQ], bufb[RW][NQ];
-  fetch(row0, bufa);
-  for (;;) {
-    const bool more1 = row0 + stride < rows;
-    if (more1) fetch(row0 + stride, bufb);
-    reduce(row0, bufa);
-    if (!more1) break;
-    row0 += stride;
-    const bool more2 = row0 + stride < rows;
-    if (more2) fetch(row0 + stride, bufa);
-    reduce(row0, bufb);
-    if (!more2) break;
-    row0 += stride;
+  for (int q = 0; q < NQ; ++q) {
+    const int i = lane + 64 * q;
+    v[q] = (i < n4) ? (f4)x4[i] : ninf;
   }
+  float m = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) m = fmaxf(fmaxf(m, fmaxf(v[q][0], v[q][1])), fmaxf(v[q][2], v[q][3]));
+  m = wave_max(m);
+  float sum = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (lane + 64 * q < n4)   // same per-lane order as the two-pass kernel
+      sum += __expf(v[q][0] - m) + __expf(v[q][1] - m) + __expf(v[q][2] - m) + __expf(v[q][3] - m);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) lse[row] = m + __logf(sum);
 }
 
 // logsumexp of each row of length C; rows = B*T*r.  One wave per row (any C).
@@ -229,12 +204,10 @@ int lse_rows(const float* logits, float* lse, size_t rows, int C, hipStream_t st
   if (rows == 0) return FTR_OK;
   const int wpb = 4;
   const unsigned blocks = (unsigned)((rows + wpb - 1) / wpb);
-  constexpr int RW = 2;
-  const size_t want = (rows + (size_t)wpb * RW - 1) / ((size_t)wpb * RW);
-  const unsigned blocks_reg = (unsigned)(want < 2048 ? want : 2048);   // 8 blocks of 4 waves per CU, grid-stride
-  if ((C & 3) == 0 && C <= 256) hipLaunchKernelGGL((lse_rows_reg_kernel<1, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
-  else if ((C & 3) == 0 && C <= 512) hipLaunchKernelGGL((lse_rows_reg_kernel<2, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
-  else if ((C & 3) == 0 && C <= 1024) hipLaunchKernelGGL((lse_rows_reg_kernel<4, RW>), dim3(blocks_reg), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  if ((C & 3) == 0 && C <= 256) hipLaunchKernelGGL((lse_rows_reg_kernel<1>), dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 512) hipLaunchKernelGGL((lse_rows_reg_kernel<2>), dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 1024) hipLaunchKernelGGL((lse_rows_reg_kernel<4>), dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
+  else if ((C & 3) == 0 && C <= 2048) hipLaunchKernelGGL((lse_rows_reg_kernel<8>), dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else if ((C & 3) == 0) hipLaunchKernelGGL(lse_rows_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   else hipLaunchKernelGGL(lse_rows_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, logits, lse, rows, C);
   return check_launch("lse_rows");
