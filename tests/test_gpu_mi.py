@@ -542,11 +542,14 @@ def _band_case(ft, dev, B, T, S, r, modified, seed, offsets=False, break_end=Fal
                                   dict(B=2, T=24, S=9, r=1), dict(B=2, T=50, S=30, r=15), dict(B=2, T=50, S=30, r=9, offsets=True),
                                   dict(B=2, T=40, S=20, r=3, break_end=True), dict(B=2, T=6, S=40, r=8), dict(B=1, T=300, S=100, r=8, offsets=True),
                                   dict(B=2, T=2200, S=500, r=5), dict(B=1, T=1500, S=700, r=10, offsets=True)])
-def test_band_recursion_kernel_edge_cases(ft, dev, case, modified):
-    """ftr_mutual_information_band_f32 directly against the full-lattice kernels on the lattices the band expands to:
+@pytest.mark.parametrize("impl", ["chain", "segments"])
+def test_band_recursion_kernel_edge_cases(ft, dev, case, modified, impl, monkeypatch):
+    """ftr_mutual_information_band_ws_f32 directly against the full-lattice kernels on the lattices the band expands to:
     begin / end offsets inside the band, S = 0, T = 1, one-row bands, 16-lane chains (r > 8), bands that never reach the end
-    cell (ans = -inf on both routes, zero occupancies), lattices taller than long; the last two are too long for LDS and
-    run through the streaming kernel (workspace in global memory)."""
+    cell (ans = -inf on both routes, zero occupancies), lattices taller than long; the last two are too long for LDS (the
+    streaming chain kernel, workspace in global memory).  Both implementations of the band recursion on every case: the chain
+    kernels of mi_band.hip and the segmented route of mi_band_seg.hip (which the library itself takes from S + T >= 1400)."""
+    monkeypatch.setenv("FTR_BAND_IMPL", impl)
     a, gx, gy, la, egx, egy, fin = _band_case(ft, dev, modified=modified, seed=5, **case)
     assert np.array_equal(np.isfinite(a), fin)
     if fin.any():
@@ -596,5 +599,18 @@ def test_streaming_band_kernel_on_every_size(dev):
                          "band_recursion_kernel_edge_cases", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
     r2 = subprocess.run([sys.executable, os.path.join(root, "scripts", "band_fuzz.py"), "150", "31"], env=env, cwd=root, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0 and "band route == lattice route" in r2.stdout, r2.stdout[-2000:] + r2.stderr[-2000:]
+
+
+def test_segmented_band_route_on_every_size(dev):
+    """The segmented band recursion (mi_band_seg.hip: transfer matrices per segment, float64 chains, occupancies as
+    exp(p + q - ans)) forced onto every size by FTR_BAND_IMPL=segments -- the library itself takes it from S + T >= 1400 --
+    through the whole pruned loss: the route-vs-route fuzz of scripts/band_fuzz.py (random shapes down to T = 1, both types,
+    ragged boundaries, r up to 20) against the full-lattice route."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FTR_BAND_IMPL="segments")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "scripts", "band_fuzz.py"), "150", "77"], env=env, cwd=root, capture_output=True,
                         text=True, timeout=600)
     assert r2.returncode == 0 and "band route == lattice route" in r2.stdout, r2.stdout[-2000:] + r2.stderr[-2000:]

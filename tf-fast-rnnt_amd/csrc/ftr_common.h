@@ -153,6 +153,9 @@ int mi_band_supported(int T, int S, int r);
 int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st);
 int band_gather(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, const float* lse, int blank, double delay_penalty, float* pxb, float* pyb, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 size_t mi_band_workspace_floats(int B, int T, int S, int r);
+int mi_band_seg_supported(int T, int S, int r);
+size_t mi_band_seg_workspace_floats(int B, int T, int S, int r);
+int mi_band_seg(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ws, size_t ws_floats, float* ans, float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st);
 int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int32_t* boundary, float* ws, size_t ws_floats, float* ans, float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st);
 int band_grad_banded(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gxb, const float* gyb, Scale scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int selftest(hipStream_t st, int* result_dev);

@@ -788,10 +788,16 @@ int mi_band_supported(int T, int S, int r) {
   if (!force_stream && band_lanes(T, S, r) != 0) return 1;
   return (T >= 1 && S >= 0 && band_stream_lanes(T, r) != 0) ? 2 : 0;
 }
-size_t mi_band_workspace_floats(int B, int T, int S, int r) {
+// the chain kernels' need (0 for the LDS-resident one)
+static size_t band_chain_workspace_floats(int B, int T, int S, int r) {
   if (mi_band_supported(T, S, r) != 2) return 0;
   const size_t per = band_stream_lanes(T, r) == 8 ? band_stream_floats_per_utt<8>(T, S) : band_stream_floats_per_utt<16>(T, S);
   return per * (size_t)B;
+}
+// what a caller should provide: enough for the segmented route (mi_band_seg.hip) where it applies, else for the chain kernels
+size_t mi_band_workspace_floats(int B, int T, int S, int r) {
+  const size_t chain = band_chain_workspace_floats(B, T, S, r), seg = mi_band_seg_workspace_floats(B, T, S, r);
+  return seg > chain ? seg : chain;
 }
 
 int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st) {
@@ -817,10 +823,13 @@ int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int
             float* ans, float* gxb, float* gyb, int B, int T, int S, int r, int modified, hipStream_t st) {
   const int kind = mi_band_supported(T, S, r);
   if (!kind) { set_error("mutual_information_band: T=%d S=%d r=%d is outside the band kernels' domain (r <= 15)", T, S, r); return FTR_ERR_UNSUPPORTED; }
+  // the segmented route (mi_band_seg.hip) whenever the caller's workspace is large enough for it
+  if (mi_band_seg_supported(T, S, r) && ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_floats >= mi_band_seg_workspace_floats(B, T, S, r))
+    return mi_band_seg(pxb, pyb, ranges, boundary, ws, ws_floats, ans, gxb, gyb, B, T, S, r, modified, st);
   if ((uint64_t)(T + 1) * r * r >= (1ull << 32)) { set_error("mutual_information_band: T * r too large"); return FTR_ERR_UNSUPPORTED; }
   const unsigned rinv = (r == 1) ? 0u : (unsigned)(((1ull << 32) + r - 1) / r);   // i / r == umulhi(i, rinv) while i * (r - 1) < 2^32; 0 stands for r = 1
   if (kind == 2) {
-    const size_t need = mi_band_workspace_floats(B, T, S, r);
+    const size_t need = band_chain_workspace_floats(B, T, S, r);
     if (!ws || ws_floats < need || (reinterpret_cast<uintptr_t>(ws) & 15) != 0) {
       set_error("mutual_information_band: this size streams through a workspace of %zu floats (16-byte aligned), got %zu", need, ws_floats);
       return FTR_ERR_INVALID_ARG;
