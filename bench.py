@@ -158,7 +158,8 @@ CALL_KERNELS = {
     "ftr_pruned_logprobs_fwd_f32": ["lse_rows_reg_kernel<2>", "band_to_lattice_kernel<false>"],
     "ftr_pruned_band_fwd_f32": ["lse_rows_reg_kernel<2>", "band_gather_kernel<false>"],
     "ftr_mutual_information_band_f32": ["mi_band_kernel<false, 8>"],
-    "ftr_mutual_information_band_ws_f32": ["mi_band_kernel<false, 8>"],
+    "ftr_mutual_information_band_ws_f32": ["band_seg_init_kernel<false, 8>", "band_seg_scatter_kernel<false, 8>", "band_seg_transfer_kernel<false, 8>",
+                                           "band_seg_prefix_kernel<false, 8>", "band_seg_final_kernel<false, 8>", "band_seg_occupancy_kernel<false, 8>"],
     "ftr_pruned_band_bwd_scaled_f32": ["band_grad_banded_kernel<true>"],
     "ftr_pruned_logprobs_bwd_f32": ["band_grad_kernel<false, true>"],
     "ftr_pruned_logprobs_bwd_scaled_f32": ["band_grad_kernel<false, true>"],

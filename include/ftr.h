@@ -393,10 +393,10 @@ int ftr_smoothed_logprobs_bwd_am_scaled_f32(const float* gpx, const float* gpy, 
  * keeps its wavefront-ordered arrays in a caller-provided workspace of ftr_mutual_information_band_workspace_floats()
  * floats (16-byte aligned; contents need not survive the call) -- pass it to ftr_mutual_information_band_ws_f32;
  * 0 = outside both (r > 15).  ftr_mutual_information_band_f32 is the _ws form without a workspace (kind 1 only).
- * From S + T >= 1400 the library runs the recursion in PARALLEL SEGMENTS instead (csrc/mi_band_seg.hip: transfer matrices of
+ * From S + T >= 1100 the library runs the recursion in PARALLEL SEGMENTS instead (csrc/mi_band_seg.hip: transfer matrices of
  * <= 32 segments per direction, float64 chains, occupancies as exp(p + q - ans); c4 124 -> 67 us, c5 527 -> 146 us) whenever
  * the workspace it is given is large enough for that: ftr_mutual_information_band_workspace_floats() returns the larger of
- * the two needs (c3: 0 -- the LDS kernel wins there --, c4 20.7 MB, c5 39.2 MB), a caller that passes less gets the chain
+ * the two needs (c3 11.7 MB, c4 21.3 MB, c5 39.2 MB; 0 below S + T = 1100 where the LDS kernel wins), a caller that passes less gets the chain
  * kernels.  FTR_BAND_IMPL = chain | segments forces one implementation for every size (tests, measurements).
  */
 int ftr_mutual_information_band_supported(int T, int S, int r);

@@ -548,7 +548,7 @@ def test_band_recursion_kernel_edge_cases(ft, dev, case, modified, impl, monkeyp
     begin / end offsets inside the band, S = 0, T = 1, one-row bands, 16-lane chains (r > 8), bands that never reach the end
     cell (ans = -inf on both routes, zero occupancies), lattices taller than long; the last two are too long for LDS (the
     streaming chain kernel, workspace in global memory).  Both implementations of the band recursion on every case: the chain
-    kernels of mi_band.hip and the segmented route of mi_band_seg.hip (which the library itself takes from S + T >= 1400)."""
+    kernels of mi_band.hip and the segmented route of mi_band_seg.hip (which the library itself takes from S + T >= 1100)."""
     monkeypatch.setenv("FTR_BAND_IMPL", impl)
     a, gx, gy, la, egx, egy, fin = _band_case(ft, dev, modified=modified, seed=5, **case)
     assert np.array_equal(np.isfinite(a), fin)
@@ -605,7 +605,7 @@ def test_streaming_band_kernel_on_every_size(dev):
 
 def test_segmented_band_route_on_every_size(dev):
     """The segmented band recursion (mi_band_seg.hip: transfer matrices per segment, float64 chains, occupancies as
-    exp(p + q - ans)) forced onto every size by FTR_BAND_IMPL=segments -- the library itself takes it from S + T >= 1400 --
+    exp(p + q - ans)) forced onto every size by FTR_BAND_IMPL=segments -- the library itself takes it from S + T >= 1100 --
     through the whole pruned loss: the route-vs-route fuzz of scripts/band_fuzz.py (random shapes down to T = 1, both types,
     ragged boundaries, r up to 20) against the full-lattice route."""
     import os, subprocess, sys

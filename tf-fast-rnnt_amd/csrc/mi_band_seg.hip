@@ -190,6 +190,32 @@ struct SegBand {
   __device__ int slotB(int s, int t) const { return (kRow0 + dgB(s, t)) * LANES + ((se - s) & (LANES - 1)); }
 };
 
+// operands of band cell (s, t): (ax, ay) = the transitions INTO it (chain A's slot), (bx, by) = the transitions OUT of it
+// (chain B's slot); log2 domain, shifted; kNeg where the transition does not exist, leaves the rectangle or leaves the band.
+// l0 / lm / lp: band start of columns t, t - 1, t + 1.
+template <bool MOD, int LANES>
+__device__ __forceinline__ void seg_cell_operands(const SegBand<MOD, LANES>& g, const float* __restrict__ pxu, const float* __restrict__ pyu,
+                                                  float cx2, float cy2, int s, int t, int l0, int lm, int lp,
+                                                  float& ax, float& ay, float& bx, float& by) {
+  const int r = g.r, sb = g.sb, tb = g.tb, se = g.se, te = g.te;
+  auto at = [&](const float* src, float c2, int ss, int tt, int l) { return __builtin_fmaf(src[(size_t)tt * r + (ss - l)], kLog2e, -c2); };
+  ax = kNeg; ay = kNeg; bx = kNeg; by = kNeg;
+  {
+    const int tx = MOD ? t - 1 : t;
+    const int lx = MOD ? lm : l0;
+    if (s - 1 >= sb && tx >= tb && tx <= te - 1 && g.in_band(s - 1, tx, lx)) ax = at(pxu, cx2, s - 1, tx, lx);
+    if (t - 1 >= tb && g.in_band(s, t - 1, lm)) ay = at(pyu, cy2, s, t - 1, lm);
+    if (s == sb && t == tb) ay = 0.0f;                               // origin trick
+  }
+  if (t <= te - 1) {
+    const int tnx = MOD ? t + 1 : t;
+    const int ln = MOD ? lp : l0;
+    if (s + 1 <= se && tnx <= te && g.in_band(s + 1, tnx, ln)) bx = at(pxu, cx2, s, t, l0);
+    if (g.in_band(s, t + 1, lp)) by = at(pyu, cy2, s, t, l0);
+  }
+  if (s == se && t == te) by = 0.0f;                                 // chain B's origin is the end cell
+}
+
 template <bool MOD, int LANES>
 __global__ __launch_bounds__(256) void band_seg_scatter_kernel(const float* __restrict__ pxb, const float* __restrict__ pyb,
                                                                const int32_t* __restrict__ ranges, const int32_t* __restrict__ boundary,
@@ -218,26 +244,10 @@ __global__ __launch_bounds__(256) void band_seg_scatter_kernel(const float* __re
   };
   const int s = l0 + k;
   if (s >= sb && s <= se) {
-    {   // chain A: the transitions INTO the cell
-      float ax = kNeg, ay = kNeg;
-      const int tx = MOD ? t - 1 : t;
-      const int lx = MOD ? lm : l0;
-      if (s - 1 >= sb && tx >= tb && tx <= te - 1 && g.in_band(s - 1, tx, lx)) ax = at(pxu, cx2, s - 1, tx, lx);
-      if (t - 1 >= tb && g.in_band(s, t - 1, lm)) ay = at(pyu, cy2, s, t - 1, lm);
-      if (s == sb && t == tb) ay = 0.0f;                               // origin trick
-      put(w.OA, g.slotA(s, t), ax, ay);
-    }
-    {   // chain B: the transitions OUT of the cell
-      float bx = kNeg, by = kNeg;
-      if (t <= te - 1) {
-        const int tnx = MOD ? t + 1 : t;
-        const int ln = MOD ? lp : l0;
-        if (s + 1 <= se && tnx <= te && g.in_band(s + 1, tnx, ln)) bx = at(pxu, cx2, s, t, l0);
-        if (g.in_band(s, t + 1, lp)) by = at(pyu, cy2, s, t, l0);
-      }
-      if (s == se && t == te) by = 0.0f;                               // chain B's origin is the end cell
-      put(w.OB, g.slotB(s, t), bx, by);
-    }
+    float ax, ay, bx, by;
+    seg_cell_operands<MOD, LANES>(g, pxu, pyu, cx2, cy2, s, t, l0, lm, lp, ax, ay, bx, by);
+    put(w.OA, g.slotA(s, t), ax, ay);
+    put(w.OB, g.slotB(s, t), bx, by);
   }
   // the end cell outside the band of column t_end (modified type, see mi_band.hip): reached by the last frame's top px only
   if (g.end_above && i == 0) {
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(256) void band_seg_occupancy_kernel(const int32_t* 
 }
 
 inline int seg_lanes(int r) { return r <= 7 ? 8 : (r <= 15 ? 16 : 0); }
+constexpr int kSegFrom = 1100;   // S + T from which this route is taken (below: the chain kernels of mi_band.hip)
 inline size_t seg_lds_bytes(int T, int S, int lanes, bool store) {
   const size_t L = (size_t)seg_lmax(T, S);
   return sizeof(float2) * (L + 2 * kSegU) * lanes + (store ? sizeof(double) * (L * lanes) : 0) + 64;
@@ -447,15 +458,19 @@ inline size_t seg_lds_bytes(int T, int S, int lanes, bool store) {
 }  // namespace
 
 // 0 unless the segmented route covers the shape (r <= 15, the segment's operands fit LDS) AND pays: its six launches cost
-// ~50 us whatever the size, the chain kernels 43 ns per walk step -- measured (scripts/band_bench.py, one MI355X):
-//   S + T = 1200 (c3): 53.7 us against 57.2     2300 (c4): 66.5 against 124.1     9000 (c5): 145.7 against 526.6
-// so it is taken from S + T >= 1400.  FTR_BAND_IMPL = chain | segments forces one (tests, A/B measurements).
+// ~45 us whatever the size, the chain kernels 43 ns per walk step -- measured (scripts/band_bench.py, one MI355X, B = 32 / 8):
+//   S + T =  480: 39.3 us against 28.4     850: 44.8 against 43.5     1200 (c3): 51.0 against 57.1
+//           1800: 60.4 against 100.0      2300 (c4): 65.8 against 123.4      9000 (c5): 145.7 against 526.6
+// so it is taken from S + T >= 1100 (in the c3 step: 60.8 -> 53.8 us).  FTR_BAND_IMPL = chain | segments forces one (tests,
+// A/B measurements).  (A single-launch form for bands whose operands fit LDS -- scatter, matrices, states and chains of one
+// direction in one 16-wave workgroup -- was built and measured: 29.9 / 41.2 / 52.4 / 70.4 us at the first four sizes, never
+// better than the better of the other two, because a float64 chain step costs 125 ns where the float32 one costs 43; dropped.)
 int mi_band_seg_supported(int T, int S, int r) {
   bool forced = false;
   if (const char* e = getenv("FTR_BAND_IMPL")) { if (!strcmp(e, "chain")) return 0; forced = !strcmp(e, "segments"); }
-  if (!forced && (long long)S + T < 1400) return 0;
   const int lanes = seg_lanes(r);
   if (!lanes || T < 1 || S < 0 || r < 1) return 0;
+  if (!forced && (long long)S + T < kSegFrom) return 0;
   if (seg_lds_bytes(T, S, lanes, true) > (size_t)150 * 1024) return 0;
   if ((uint64_t)(T + 1) * r >= (1ull << 31) || (uint64_t)seg_rows(T, S) * lanes >= (1ull << 31)) return 0;
   return 1;
