@@ -719,8 +719,12 @@ __global__ void band_grad_banded_kernel(const float* __restrict__ logits, const 
                                         const float* __restrict__ gyb, const Scale scale, int blank, int modified,
                                         float* __restrict__ glogits, size_t rows, int T, int S, int C, int r) {
   const int lane = threadIdx.x & 63;
-  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  // LAST ROWS FIRST: the caller's backward reads `glogits` front to back right after this kernel, and what a 320 MB stream
+  // leaves in the 256 MB memory-side cache is what was written last (see lse_rows_reg_kernel, pruned_logprobs.hip): 121 -> 117 us
+  // here and 2 us off the caller's next kernel in the c3 step (scripts/order_ab.sh)
+  const size_t rowi = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (rowi >= rows) return;
+  const size_t row = rows - 1 - rowi;
   const size_t bt = row / r;
   const int k = (int)(row - bt * r);
   const int b = (int)(bt / T);
@@ -824,7 +828,7 @@ int mi_band(const float* pxb, const float* pyb, const int32_t* ranges, const int
   const int kind = mi_band_supported(T, S, r);
   if (!kind) { set_error("mutual_information_band: T=%d S=%d r=%d is outside the band kernels' domain (r <= 15)", T, S, r); return FTR_ERR_UNSUPPORTED; }
   // the segmented route (mi_band_seg.hip) whenever the caller's workspace is large enough for it
-  if (mi_band_seg_supported(T, S, r) && ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_floats >= mi_band_seg_workspace_floats(B, T, S, r))
+  if (B <= 65535 && mi_band_seg_supported(T, S, r) && ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_floats >= mi_band_seg_workspace_floats(B, T, S, r))
     return mi_band_seg(pxb, pyb, ranges, boundary, ws, ws_floats, ans, gxb, gyb, B, T, S, r, modified, st);
   if ((uint64_t)(T + 1) * r * r >= (1ull << 32)) { set_error("mutual_information_band: T * r too large"); return FTR_ERR_UNSUPPORTED; }
   const unsigned rinv = (r == 1) ? 0u : (unsigned)(((1ull << 32) + r - 1) / r);   // i / r == umulhi(i, rinv) while i * (r - 1) < 2^32; 0 stands for r = 1

@@ -24,8 +24,13 @@ template <int NQ>
 __global__ __launch_bounds__(256) void lse_rows_reg_kernel(const float* __restrict__ logits, float* __restrict__ lse,
                                                            size_t rows, int C) {
   const int lane = threadIdx.x & 63;
-  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  // LAST ROWS FIRST.  The joiner has just written `logits` front to back, 320 MB at c3 against 256 MB of memory-side cache:
+  // what is still in the cache is the tail.  Walking front to back misses the cache on the head AND pushes the dirty tail out
+  // before it is read; walking back to front reads the tail from the cache: 75 -> 53 us inside the c3 step (the kernel alone,
+  // on a tensor at rest, takes 55 us either way).
+  const size_t rowi = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (rowi >= rows) return;
+  const size_t row = rows - 1 - rowi;
   const int n4 = C >> 2;
   const f4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   const f4u* x4 = reinterpret_cast<const f4u*>(logits + row * C);
