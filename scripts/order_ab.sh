@@ -1,5 +1,4 @@
-# A/B of the "last rows first" order of a streaming kernel inside the step: product against a study build (e.g.
-#   make -C tf-fast-rnnt_amd/csrc variant NAME=x SRC=pruned_logprobs DEFS=-D...), VARIANT=x bash scripts/order_ab.sh
+# A/B of a study build inside the step: product against _build/libftr_$VARIANT.so (make -C tf-fast-rnnt_amd/csrc variant ...)
 for cfg in ${CFGS:-c3}; do
 for v in product ${VARIANT:-product} product ${VARIANT:-product}; do
   if [ $v = product ]; then unset FTR_LIB_PATH; else export FTR_LIB_PATH=$PWD/tf-fast-rnnt_amd/csrc/_build/libftr_$v.so; fi
@@ -7,6 +6,6 @@ for v in product ${VARIANT:-product} product ${VARIANT:-product}; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/b10.json")); k=d["kernels"]
-print("$cfg $v", d["ms_per_step"], "joiner", round(d["joiner_standin_us_per_step"],1), {n[4:]: k[n]["avg_us"] for n in ("ftr_do_pruning_f32","ftr_pruned_band_fwd_f32","ftr_pruned_band_bwd_scaled_f32","ftr_do_pruning_bwd_ws_f32")})
+print("$cfg $v", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["avg_launch_us_each"])
 PY
 done; done

@@ -710,9 +710,20 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
     // by the COMM wave, three chunks ahead)
     int frame_k = 0;
     const bool lane_valid = 64 * w + lane < Sn;
+    // TOUCH.  A chunk's 16 granules are one 128-byte line.  Inside a training step the memory-side cache is full of other
+    // kernels' dirty lines, and a write-through store to a line that is NOT in it has to make room first -- the late
+    // visibility of the hand-off that costs the chained bands 8 - 14 us per launch inside the step.  So this wave,
+    // which never waits for a load, reads one granule of each of this band's INCOMING lines during its first slots (64 lines
+    // per slot: the whole region of c3 in one slot, of c5 in eight), long before the band above publishes into most of them:
+    // the loads take the misses, off everybody's critical path, and the stores find their lines.  (From the COMM wave the same
+    // loads are harmful: vmcnt retires in order, so its next import waits behind them -- c5 +65 / +85 us.)
+    u64 touched = 0;
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int k = kc - 1;                 // the chunk the compute wave finished in the previous slot
+#ifndef FTR_EXP_NOTOUCH
+      if (has_up && 64 * gg + lane < klast_up) touched = __hip_atomic_load(gran_in + CH * (64 * gg + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       if (k >= 0 && k < klast) {
         const float* tp = reinterpret_cast<const float*>(FTR_TP(k));
         // chunk 0: the base frame the COMM wave chose (slots ago) counts as chunk 0's step
@@ -741,6 +752,7 @@ __device__ __forceinline__ void bidir_fwd_body(unsigned char* smem, const float*
       FTR_SYNC();
     }
     clear_imported(base + NIT * NPF - 1 + LOOK);
+    asm volatile("" ::"v"(touched));
     FTR_SYNC_REPORT(3);
     return;
   }
@@ -1257,9 +1269,13 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
     // max(kfirst_up, its kfirst - PRE + LOOK) on, with its jli = jli - 64 * SKEW
     const int kpub = max(kfirst, max(jli - 64 * SKEW, 0) / CH - PRE + LOOK);
     auto clear_imported = [&](int mm) { if (has_up && mm >= kfirst_up && mm < nchunks) comm_clear(gran_in, mm, lane); };
+    u64 touched = 0;   // this band's incoming hand-off lines are read once, early (see the forward kernel's IO-out wave: TOUCH)
     for (int gg = 0; gg < NIT * NPF; ++gg) {
       const int kc = base + gg;
       const int k = kc - 1;
+#ifndef FTR_EXP_NOTOUCH
+      if (has_up && kfirst_up + 64 * gg + lane < nchunks) touched = __hip_atomic_load(gran_in + CH * (kfirst_up + 64 * gg + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       if (k >= kfirst && k < nchunks) {
         if (has_down && k >= kpub && lane < CH) {
           const float* txo = reinterpret_cast<const float*>(FTR_TXO(k));
@@ -1282,6 +1298,7 @@ __device__ __forceinline__ void bidir_flow_body(unsigned char* smem, const Bound
       FTR_FSYNC();
     }
     clear_imported(base + NIT * NPF - 1 + LOOK);
+    asm volatile("" ::"v"(touched));
     FTR_FREPORT(3);
     return;
   }
