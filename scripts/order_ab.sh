@@ -1,4 +1,5 @@
-# A/B of a study build inside the step: product against _build/libftr_$VARIANT.so (make -C tf-fast-rnnt_amd/csrc variant ...)
+# A/B of a study build inside the step: product against _build/libftr_$VARIANT.so (make -C tf-fast-rnnt_amd/csrc variant ...),
+# optionally with FTR_PRUNE_SEG set for both; prints ms per step and the calls whose order of walking memory was studied
 for cfg in ${CFGS:-c3}; do
 for v in product ${VARIANT:-product} product ${VARIANT:-product}; do
   if [ $v = product ]; then unset FTR_LIB_PATH; else export FTR_LIB_PATH=$PWD/tf-fast-rnnt_amd/csrc/_build/libftr_$v.so; fi
@@ -6,6 +7,6 @@ for v in product ${VARIANT:-product} product ${VARIANT:-product}; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/b10.json")); k=d["kernels"]
-print("$cfg $v", d["ms_per_step"], "frac", d["roofline"]["frac"], d["roofline"]["avg_launch_us_each"])
+print("$cfg $v seg=${FTR_PRUNE_SEG:-default}", d["ms_per_step"], {n[4:]: k[n]["avg_us"] for n in ("ftr_do_pruning_f32","ftr_pruned_band_fwd_f32","ftr_pruned_band_bwd_scaled_f32","ftr_do_pruning_bwd_ws_f32")})
 PY
 done; done

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(128) void do_pruning_bwd_seg_kernel(
   extern __shared__ int bs[];      // base[SEG]
   __shared__ int red[8];
   constexpr int r = R;
-  const int seg = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;   // (last segments first, as lse_rows_reg_kernel walks its rows, was measured: no effect here)
+  const int seg = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;   // (last segments first, as lse_rows_reg_kernel walks its rows, was measured: 93 - 97 us either way)
   const int t0 = seg * SEG;
   const int nf = min(SEG, T - t0);
   const int nrows = nf * r;
