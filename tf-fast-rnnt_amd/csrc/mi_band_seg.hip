@@ -325,6 +325,9 @@ __global__ __launch_bounds__(16 * LANES) void band_seg_transfer_kernel(const int
   if (l16 < LANES) m[basis * LANES + lg] = val;
 }
 
+// (Folding this kernel into the transfer kernel -- the workgroup of a chain that finishes last, found with a counter behind a
+// __threadfence(), does the products -- was built and is 70 us SLOWER at c3: a device-scope fence on this part writes back
+// the whole L2 of its XCD, once per workgroup.  Kernel boundaries do that once.)
 // grid (2, B), one wave: the initial state of every segment -- the start cell (lane 0 = 0) pushed through the matrices one
 // after the other: s'[o] = log2 sum_i 2^(s[i] + M_g[i][o]) (double; only the bounded differences go through the float32
 // exp2 / log2).  All matrices are brought into LDS first: the K - 1 products are a dependent chain, their loads are not.
