@@ -166,6 +166,7 @@ CALL_KERNELS = {
     "ftr_simple_logprobs_bwd_w_scaled_f32": ["simple_bwd_w_kernel<false>"],
     "ftr_simple_logprobs_bwd_am_scaled_f32": ["simple_bwd_am_kernel<false, 16>"],
     "ftr_rowmax_exp_f32": ["rowmax_exp_kernel<true>"],
+    "ftr_rowmax_exp_pair_f32": ["rowmax_exp_pair_kernel<true>"],
     "ftr_simple_logprobs_fwd_f32": ["simple_fwd_kernel<false, 16>"],
     "ftr_simple_logprobs_fused_fwd_f32": ["simple_fused_fwd_kernel<false, false, 13>"],
     "ftr_simple_logprobs_fused_bwd_am_f32": ["simple_fused_bwd_am_kernel<false>"],
@@ -202,6 +203,7 @@ def algorithmic_bytes(B, T, S, C, r):
     return {
         # simple/smoothed builder ("report bytes and flops separately; it is not the headline")
         "ftr_rowmax_exp_f32": 4 * (nam + nlm),                              # mean of the am call and the lm call: read + write
+        "ftr_rowmax_exp_pair_f32": 8 * (nam + nlm),                         # am and lm in one launch: read + write
         "ftr_rowmax_exp_sum_f32": 4 * 2 * nlm,
         "ftr_rowmax_exp_dot_f32": 4 * 2 * nam,                              # am read, am_probs written (+ the dot for free)
         "ftr_colsum_weighted_f32": 4 * (nam + nlm) // 2,                    # mean of the lm_probs call (fwd) and the am_probs call (bwd)

@@ -209,6 +209,9 @@ int ftr_pruned_logprobs_bwd_f32(const float* logits, const int32_t* symbols, con
  * gpx' = gpx with the cells the forward overwrote with -inf (t == T, t == t_end; regular only) masked out.
  */
 int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long rows, int C, void* stream);
+/* the same for two matrices of C columns in one launch (am [B*T,C] and lm [B*(S+1),C] of the simple builder) */
+int ftr_rowmax_exp_pair_f32(const float* x1, float* probs1, float* rowmax1, long long rows1, const float* x2, float* probs2,
+                            float* rowmax2, long long rows2, int C, void* stream);
 int ftr_simple_logprobs_fwd_f32(const float* am, const float* lm, const int32_t* symbols, const float* prod,
                                 const float* am_max, const float* lm_max, const int32_t* boundary,
                                 int termination_symbol, double delay_penalty, float* px, float* py, int B, int T,

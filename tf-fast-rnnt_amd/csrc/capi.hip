@@ -62,7 +62,7 @@ using namespace ftr;
 
 extern "C" {
 
-int ftr_abi_version(void) { return 131; }
+int ftr_abi_version(void) { return 132; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
@@ -280,6 +280,17 @@ int ftr_rowmax_exp_f32(const float* x, float* probs, float* rowmax, long long ro
   int rc = device_ok();
   if (rc != FTR_OK) return rc;
   return simple_rowmax_exp(x, probs, rowmax, nullptr, nullptr, nullptr, (size_t)rows, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+int ftr_rowmax_exp_pair_f32(const float* x1, float* probs1, float* rowmax1, long long rows1, const float* x2, float* probs2,
+                            float* rowmax2, long long rows2, int C, void* stream) {
+  clear_error();
+  FTR_REQUIRE(rows1 >= 0 && rows2 >= 0 && C >= 0, "rowmax_exp_pair: negative size");
+  if (rows1 + rows2 == 0 || C == 0) return FTR_OK;
+  FTR_REQUIRE((rows1 == 0 || (x1 && probs1 && rowmax1)) && (rows2 == 0 || (x2 && probs2 && rowmax2)), "rowmax_exp_pair: null pointer");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return simple_rowmax_exp_pair(x1, probs1, rowmax1, (size_t)rows1, x2, probs2, rowmax2, (size_t)rows2, C, reinterpret_cast<hipStream_t>(stream));
 }
 
 int ftr_rowmax_exp_sum_f32(const float* x, float* probs, float* rowmax, float* rowsum, long long rows, int C,

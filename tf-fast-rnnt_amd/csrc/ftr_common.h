@@ -133,6 +133,7 @@ int do_pruning_bwd(const float* g_am_p, const float* g_lm_p, const int32_t* rang
 int pruned_logprobs_fwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, double delay_penalty, float* lse, float* px, float* py, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int pruned_logprobs_bwd(const float* logits, const int32_t* symbols, const int32_t* ranges, const int32_t* boundary, int blank, const float* lse, const float* gpx, const float* gpy, Scale scale, float* glogits, int B, int T, int S, int C, int r, int modified, hipStream_t st);
 int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum, const float* dotvec, float* dot, size_t rows, int C, hipStream_t st);
+int simple_rowmax_exp_pair(const float* x1, float* probs1, float* rowmax1, size_t rows1, const float* x2, float* probs2, float* rowmax2, size_t rows2, int C, hipStream_t st);
 int simple_rowdot(const float* x, const float* v, float* dot, size_t rows, int C, hipStream_t st);
 size_t simple_colsum_workspace_floats(size_t rows, int C);
 int simple_colsum_weighted(const float* x, const float* w, float* out, float* ws, size_t ws_floats, size_t rows, int C, hipStream_t st);

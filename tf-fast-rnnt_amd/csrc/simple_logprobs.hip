@@ -35,12 +35,9 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 // and dot[row] = probs[row, :] . dotvec (the am-only normaliser of the smoothed builder, rnnt_loss.py:1281-1286, taken
 // while the row is in registers instead of a second pass over the [B*T, C] matrix).  One wave per row.
 template <bool VEC>
-__global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict__ probs,
-                                  float* __restrict__ rowmax, float* __restrict__ rowsum,
-                                  const float* __restrict__ dotvec, float* __restrict__ dot, size_t rows, int C) {
-  const int lane = threadIdx.x & 63;
-  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+__device__ __forceinline__ void rowmax_exp_row(const float* __restrict__ x, float* __restrict__ probs,
+                                               float* __restrict__ rowmax, float* __restrict__ rowsum,
+                                               const float* __restrict__ dotvec, float* __restrict__ dot, size_t row, int C, int lane) {
   const float* xr = x + row * C;
   float* pr = probs + row * C;
   float m = -INFINITY;
@@ -68,6 +65,27 @@ __global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict
   if (rowsum) { sum = wave_sum(sum); if (lane == 0) rowsum[row] = sum; }
   if (dotvec) { dsum = wave_sum(dsum); if (lane == 0) dot[row] = dsum; }
   if (lane == 0) rowmax[row] = m;
+}
+
+template <bool VEC>
+__global__ void rowmax_exp_kernel(const float* __restrict__ x, float* __restrict__ probs,
+                                  float* __restrict__ rowmax, float* __restrict__ rowsum,
+                                  const float* __restrict__ dotvec, float* __restrict__ dot, size_t rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  rowmax_exp_row<VEC>(x, probs, rowmax, rowsum, dotvec, dot, row, C, lane);
+}
+
+// the same for TWO matrices of C columns in one launch (am [B*T, C] and lm [B*(S+1), C] of the simple builder: the second is
+// a 3-us kernel of its own otherwise, and every kernel boundary of the step costs 1.7 us of idle time on top)
+template <bool VEC>
+__global__ void rowmax_exp_pair_kernel(const float* __restrict__ x1, float* __restrict__ probs1, float* __restrict__ rowmax1, size_t rows1,
+                                       const float* __restrict__ x2, float* __restrict__ probs2, float* __restrict__ rowmax2, size_t rows2, int C) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row < rows1) rowmax_exp_row<VEC>(x1, probs1, rowmax1, nullptr, nullptr, nullptr, row, C, lane);
+  else if (row - rows1 < rows2) rowmax_exp_row<VEC>(x2, probs2, rowmax2, nullptr, nullptr, nullptr, row - rows1, C, lane);
 }
 
 // dot[row] = x[row, :] . v.  One wave per row.
@@ -435,6 +453,16 @@ int simple_rowmax_exp(const float* x, float* probs, float* rowmax, float* rowsum
   if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, dotvec, dot, rows, C);
   else hipLaunchKernelGGL(rowmax_exp_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x, probs, rowmax, rowsum, dotvec, dot, rows, C);
   return check_launch("rowmax_exp");
+}
+
+int simple_rowmax_exp_pair(const float* x1, float* probs1, float* rowmax1, size_t rows1, const float* x2, float* probs2, float* rowmax2,
+                           size_t rows2, int C, hipStream_t st) {
+  if (rows1 + rows2 == 0 || C == 0) return FTR_OK;
+  const int wpb = 4;
+  const unsigned blocks = (unsigned)((rows1 + rows2 + wpb - 1) / wpb);
+  if ((C & 3) == 0) hipLaunchKernelGGL(rowmax_exp_pair_kernel<true>, dim3(blocks), dim3(64 * wpb), 0, st, x1, probs1, rowmax1, rows1, x2, probs2, rowmax2, rows2, C);
+  else hipLaunchKernelGGL(rowmax_exp_pair_kernel<false>, dim3(blocks), dim3(64 * wpb), 0, st, x1, probs1, rowmax1, rows1, x2, probs2, rowmax2, rows2, C);
+  return check_launch("rowmax_exp_pair");
 }
 
 int simple_rowdot(const float* x, const float* v, float* dot, size_t rows, int C, hipStream_t st) {

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ftr_simple_logprobs_bwd_w_scaled_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),
     "ftr_simple_logprobs_bwd_am_scaled_f32": (_i, [_c_fp, _c_fp, _c_fp, _i, _f, _c_fp, _c_fp, _c_ip, _c_ip, _i, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_rowmax_exp_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
+    "ftr_rowmax_exp_pair_f32": (_i, [_c_fp, _c_fp, _c_fp, ctypes.c_longlong, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
     "ftr_rowmax_exp_sum_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, _i, _c_st]),
     "ftr_smoothed_logprobs_fwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_ip, _i, _f, _f, _f, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_smoothed_logprobs_bwd_w_f32": (_i, [_c_fp, _c_fp, _c_fp, _c_ip, _f, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _c_st]),

@@ -147,8 +147,8 @@ class _SimpleLogprobs(torch.autograd.Function):
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _stream_ptr(amc)
-            _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)        # :175-178
-            _lib.call("ftr_rowmax_exp_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
+            _lib.call("ftr_rowmax_exp_pair_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T,              # :175-178
+                      _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
             prod = _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol,
                                    delay_penalty, px, py, B, T, S, C, modified, st)
         ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0))
@@ -207,8 +207,8 @@ class _SimpleLoss(torch.autograd.Function):
         py = torch.empty((B, S + 1, T), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _stream_ptr(amc)
-            _lib.call("ftr_rowmax_exp_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T, C, st)        # :175-178
-            _lib.call("ftr_rowmax_exp_f32", _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
+            _lib.call("ftr_rowmax_exp_pair_f32", _ptr(amc), _ptr(am_probs), _ptr(am_max), B * T,              # :175-178
+                      _ptr(lmc), _ptr(lm_probs), _ptr(lm_max), B * (S + 1), C, st)
             prod = _simple_builder(amc, lmc, symbols, am_probs, lm_probs, am_max, lm_max, boundary, termination_symbol,
                                    delay_penalty, px, py, B, T, S, C, modified, st)
         # the recursion backward (occupancies) only when somebody wants them: the caller (calc_gradients) or autograd
