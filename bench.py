@@ -151,6 +151,7 @@ class CallTimer:
 CALL_KERNELS = {
     "ftr_mutual_information_fwd_ws_f32": ["mi_bidir_fwd_kernel<false>"],
     "ftr_mutual_information_bwd_ws_f32": ["mi_bidir_flow_kernel<false>"],
+    "ftr_mutual_information_bwd_loss_ws_f32": ["mi_bidir_flow_kernel<false>"],
     "ftr_prune_ranges_i32": ["prune_argmax_once_kernel<5>", "prune_adjust_kernel"],
     "ftr_do_pruning_f32": ["do_pruning_kernel<true>"],
     "ftr_do_pruning_bwd_f32": ["do_pruning_bwd_am_kernel<true>", "do_pruning_bwd_lm_kernel<true>"],
@@ -231,6 +232,7 @@ def algorithmic_bytes(B, T, S, C, r):
         # fwd reads px,py and writes p; bwd (reference algorithm) reads px,py,p and writes both grads: 32 L total
         "ftr_mutual_information_fwd_ws_f32": 4 * (npx + npy + L),
         "ftr_mutual_information_bwd_ws_f32": 4 * (npx + npy + L + npx + npy),
+        "ftr_mutual_information_bwd_loss_ws_f32": 4 * (npx + npy + L + npx + npy),   # the same launch, the loss tail rides along
         "ftr_prune_ranges_i32": 4 * (npx + npy + B * T * r),
         "ftr_do_pruning_f32": 4 * (B * (S + 1) * C + B * T * r) + N,     # the gather; am_pruned stays a broadcast view of am
         "ftr_pruned_logprobs_fwd_f32": N + 4 * (npx + npy),              # stream logits once, write px,py
@@ -566,7 +568,9 @@ def main():
     # from run to run; every other native call is in `kernels`.  avg_launch_us = the HIP-event time of the two calls
     # (each call = its kernels back to back on the stream; the rocprofv3 --kernel-trace --stats summary of this same
     # command under profiles/ gives the per-kernel split).
-    pair = ("ftr_mutual_information_fwd_ws_f32", "ftr_mutual_information_bwd_ws_f32")   # the entry points the package calls
+    # the entry points the package calls (the loss nodes' backward launch also writes the reduced loss: ..._bwd_loss_ws_f32)
+    pair = ("ftr_mutual_information_fwd_ws_f32",
+            "ftr_mutual_information_bwd_loss_ws_f32" if "ftr_mutual_information_bwd_loss_ws_f32" in calls else "ftr_mutual_information_bwd_ws_f32")
     roofline = None
     traffic, traffic_file = pmc_traffic(args.config) if (first_pass == "simple" and not args.ragged) else (None, None)
     if traffic:

@@ -68,6 +68,13 @@ size_t ftr_mutual_information_handoff_floats(int B, int S, int T);
 
 /* Zeroes the hand-off region of a workspace (asynchronous on `stream`): the last handoff_floats(B,S,T) floats of
  * p[0, p_floats).  Once per buffer (see FTR_MI_WS_CLEAN). */
+/* ftr_mutual_information_bwd_ws_f32 with ans_grad = NULL (a seed of ones, no self check) that ALSO writes the loss tail of
+ * rnnt_loss.py:333,544-546 -- loss_out = -ans [B] (reduction 0), -mean(ans) (1) or -sum(ans) (2), the values
+ * ftr_negated_reduce_f32 gives, bit for bit -- from `ans` as the forward launch left it: the loss nodes' forward is
+ * fwd + this, one kernel boundary less than fwd + bwd + negated_reduce. */
+int ftr_mutual_information_bwd_loss_ws_f32(const float* px, const float* py, const int32_t* boundary, const float* p,
+                                           size_t p_floats, int flags, float* px_grad, float* py_grad, const float* ans,
+                                           int reduction, float* loss_out, int B, int S, int T, int modified, void* stream);
 int ftr_mutual_information_workspace_init(float* p, size_t p_floats, int B, int S, int T, void* stream);
 
 /* Reads back the sticky status word of a workspace (SYNCHRONISES `stream`): 0 = fine; bit 0 = some band gave up

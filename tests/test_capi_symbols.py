@@ -42,7 +42,7 @@ def test_product_library_carries_no_diagnostics(ft):
 
 def test_version_and_names(ft):
     L = ft._lib.lib()
-    assert L.ftr_abi_version() == 132
+    assert L.ftr_abi_version() == 133
     assert L.ftr_package_version() == b"1.2" and ft.__version__ == "1.2"
     # the op surface of the reference package (tf_fast_rnnt/python/tf_fast_rnnt/__init__.py:24-33,42,151)
     for name in ("do_rnnt_pruning", "get_rnnt_logprobs", "get_rnnt_logprobs_joint", "get_rnnt_logprobs_pruned",

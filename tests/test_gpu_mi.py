@@ -614,3 +614,22 @@ def test_segmented_band_route_on_every_size(dev):
     r2 = subprocess.run([sys.executable, os.path.join(root, "scripts", "band_fuzz.py"), "150", "77"], env=env, cwd=root, capture_output=True,
                         text=True, timeout=600)
     assert r2.returncode == 0 and "band route == lattice route" in r2.stdout, r2.stdout[-2000:] + r2.stderr[-2000:]
+
+
+@pytest.mark.parametrize("B", [1, 3, 64, 300])
+def test_loss_tail_inside_the_backward_launch(ft, dev, B):
+    """ftr_mutual_information_bwd_loss_ws_f32 = the backward launch (seed of ones) + the loss tail: the occupancies of
+    ftr_mutual_information_bwd_ws_f32 and -ans / -mean / -sum as ftr_negated_reduce_f32 computes them, bit for bit."""
+    from tf_fast_rnnt import _lib
+    from tf_fast_rnnt.mutual_information import mi_forward_backward
+    g = torch.Generator(device="cpu").manual_seed(B)
+    S, T = 9, 21
+    px = (torch.randn((B, S, T + 1), generator=g) - 2.0).to(dev); py = (torch.randn((B, S + 1, T), generator=g) - 1.0).to(dev)
+    ans, gx, gy = mi_forward_backward(px, py, None, True, ans_grad_is_one=True)
+    st = torch.cuda.current_stream().cuda_stream
+    for code in (0, 1, 2):
+        want = torch.empty((B,) if code == 0 else (), device=dev)
+        _lib.call("ftr_negated_reduce_f32", ans.data_ptr(), B, code, want.data_ptr(), st)
+        ans2, gx2, gy2, loss = mi_forward_backward(px, py, None, True, ans_grad_is_one=True, loss_code=code)
+        assert torch.equal(ans2, ans) and torch.equal(gx2, gx) and torch.equal(gy2, gy)
+        assert loss.shape == want.shape and torch.equal(loss, want), (code, loss, want)

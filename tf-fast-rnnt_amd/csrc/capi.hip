@@ -62,7 +62,7 @@ using namespace ftr;
 
 extern "C" {
 
-int ftr_abi_version(void) { return 132; }
+int ftr_abi_version(void) { return 133; }
 const char* ftr_package_version(void) { return "1.2"; }
 const char* ftr_last_error(void) { return g_err; }
 
@@ -157,6 +157,24 @@ int ftr_mutual_information_bwd_ws_f32(const float* px, const float* py, const in
                                       void* stream) {
   return mi_bwd_common("mutual_information_bwd_ws", px, py, boundary, p, p_floats, flags, p_grad, px_grad, py_grad, ans_grad,
                        overwrite_ans_grad, B, S, T, modified, stream);
+}
+
+int ftr_mutual_information_bwd_loss_ws_f32(const float* px, const float* py, const int32_t* boundary, const float* p,
+                                           size_t p_floats, int flags, float* px_grad, float* py_grad, const float* ans,
+                                           int reduction, float* loss_out, int B, int S, int T, int modified, void* stream) {
+  clear_error();
+  (void)px; (void)py;
+  FTR_REQUIRE(B >= 0 && S >= 0 && T >= 0, "mutual_information_bwd_loss_ws: negative size B=%d S=%d T=%d", B, S, T);
+  FTR_REQUIRE((flags & ~FTR_MI_WS_CLEAN) == 0, "mutual_information_bwd_loss_ws: unknown flag bits 0x%x", flags);
+  FTR_REQUIRE(reduction >= 0 && reduction <= 2, "mutual_information_bwd_loss_ws: reduction %d is not 0 (none), 1 (mean) or 2 (sum)", reduction);
+  if (B == 0) return FTR_OK;
+  FTR_REQUIRE(p && py_grad && ans && loss_out, "mutual_information_bwd_loss_ws: null p / py_grad / ans / loss_out");
+  FTR_REQUIRE(px_grad || S == 0 || (modified && T == 0), "mutual_information_bwd_loss_ws: null px_grad");
+  FTR_REQUIRE(mi_impl() == 0, "mutual_information_bwd_loss_ws: only with the default kernel family");
+  int rc = device_ok();
+  if (rc != FTR_OK) return rc;
+  return mi_bidir_bwd(boundary, p, p_floats, flags, px_grad, py_grad, nullptr, 0, B, S, T, modified, reinterpret_cast<hipStream_t>(stream),
+                      ans, loss_out, reduction);
 }
 
 int ftr_mutual_information_workspace_init(float* p, size_t p_floats, int B, int S, int T, void* stream) {

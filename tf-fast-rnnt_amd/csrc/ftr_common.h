@@ -119,7 +119,7 @@ namespace ftr {
 int mi_plain_fwd(const float* px, const float* py, const int32_t* boundary, float* p, float* ans, int B, int S, int T, int modified, hipStream_t st);
 int mi_plain_bwd(const float* px, const float* py, const int32_t* boundary, const float* p, float* p_grad, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
 int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, float* ws, size_t ws_floats, int flags, float* ans, int B, int S, int T, int modified, hipStream_t st);
-int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int flags, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st);
+int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int flags, float* px_grad, float* py_grad, float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st, const float* ans = nullptr, float* loss_out = nullptr, int loss_code = 0);
 int mi_bidir_ws_init(float* ws, size_t ws_floats, int B, int S, int T, hipStream_t st);
 int mi_bidir_status(const float* ws, size_t ws_floats, int B, int S, int T, int* status_host, long long* dirty_host, hipStream_t st);
 size_t mi_bidir_workspace_floats(int B, int S, int T);

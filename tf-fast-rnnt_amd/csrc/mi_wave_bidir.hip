@@ -1375,9 +1375,30 @@ template <bool MOD>
 __global__ __launch_bounds__(kFlowThreads) void mi_bidir_flow_kernel(
     const int32_t* __restrict__ boundary, const float* __restrict__ ws, u64* __restrict__ gran,
     const float* __restrict__ occ, float* __restrict__ px_grad, float* __restrict__ py_grad,
-    const float* __restrict__ seed, float* __restrict__ check, int* __restrict__ status, int B, int NB, int Tg, int S, int T) {
+    const float* __restrict__ seed, float* __restrict__ check, int* __restrict__ status, const float* __restrict__ ans,
+    float* __restrict__ loss_out, int loss_code, int B, int NB, int Tg, int S, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NOFF = MOD ? 1 : 0;
+  // The loss tail (-ans, -mean, -sum: what ftr_negated_reduce_f32 computes in a launch of its own) rides along when asked
+  // for: `ans` was finished by the forward launch, so one wave of the last workgroup -- whose band has nothing to do in most
+  // slots -- reduces it before anything else, with the additions of negated_reduce_kernel (256 virtual threads, four wave
+  // sums, (s0 + s1) + (s2 + s3)): the same bits, one kernel boundary less per loss.
+  if (loss_out && blockIdx.x == gridDim.x - 1 && threadIdx.x >= kFlowThreads - 64) {
+    const int ln = threadIdx.x & 63;
+    if (loss_code == 0) {
+      for (int i = ln; i < B; i += 64) loss_out[i] = -ans[i];
+    } else {
+      float sv[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float acc = 0.0f;
+        for (int i = 64 * v + ln; i < B; i += 256) acc += ans[i];
+        sv[v] = wave_sum_dpp(acc);
+      }
+      const float t = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+      if (ln == 0) loss_out[0] = (loss_code == 1) ? -(t / (float)B) : -t;
+    }
+  }
   const int b2 = blockIdx.x % (2 * B);
   const int w = blockIdx.x / (2 * B);
   const int dir = b2 / B, b = b2 - dir * B;
@@ -1609,7 +1630,8 @@ int mi_bidir_fwd(const float* px, const float* py, const int32_t* boundary, floa
 }
 
 int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int flags, float* px_grad, float* py_grad,
-                 float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st) {
+                 float* ans_grad, int overwrite, int B, int S, int T, int modified, hipStream_t st, const float* ans,
+                 float* loss_out, int loss_code) {
   const BidirLayout l = anchored(bidir_layout(B, S, T), ws_floats);
   int rc = check_ws("mutual_information_bwd", ws, ws_floats, l);
   if (rc != FTR_OK) return rc;
@@ -1639,8 +1661,8 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int
     if (rc != FTR_OK) return rc;
     big_ok = true;
   }
-  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl + (status_off(l) - l.ctrl_off), B, l.NB, l.Tg, S, T);
-  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl + (status_off(l) - l.ctrl_off), B, l.NB, l.Tg, S, T);
+  if (modified) hipLaunchKernelGGL(mi_bidir_flow_kernel<true>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl + (status_off(l) - l.ctrl_off), ans, loss_out, loss_code, B, l.NB, l.Tg, S, T);
+  else hipLaunchKernelGGL(mi_bidir_flow_kernel<false>, grid, dim3(kFlowThreads), lds, st, boundary, ws, gran, ws + l.occ_off, px_grad, py_grad, seed, check, ctrl + (status_off(l) - l.ctrl_off), ans, loss_out, loss_code, B, l.NB, l.Tg, S, T);
   return check_launch("mi_bidir_bwd");
 }
 

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "ftr_mutual_information_bwd_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_fwd_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, ctypes.c_size_t, _i, _c_fp, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_bwd_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, ctypes.c_size_t, _i, _c_fp, _c_fp, _c_fp, _c_fp, _i, _i, _i, _i, _i, _c_st]),
+    "ftr_mutual_information_bwd_loss_ws_f32": (_i, [_c_fp, _c_fp, _c_ip, _c_fp, ctypes.c_size_t, _i, _c_fp, _c_fp, _c_fp, _i, _c_fp, _i, _i, _i, _i, _c_st]),
     "ftr_mutual_information_workspace_init": (_i, [_c_fp, ctypes.c_size_t, _i, _i, _i, _c_st]),
     "ftr_mutual_information_status": (_i, [_c_fp, ctypes.c_size_t, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong), _c_st]),
     "ftr_cummin_i32": (_i, [_c_ip, _c_ip, _i, _i, _c_st]),

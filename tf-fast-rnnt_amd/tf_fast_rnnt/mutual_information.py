@@ -124,8 +124,10 @@ def check_workspace_status() -> int:
 
 def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[torch.Tensor],
                         need_grads: bool, ans_grad: Optional[torch.Tensor] = None,
-                        return_ans_grad_check: bool = False, ans_grad_is_one: bool = False):
-    """FastRNNTOpBase::Compute on raw tensors (no autograd).  Returns (ans, px_grad|None, py_grad|None[, check])."""
+                        return_ans_grad_check: bool = False, ans_grad_is_one: bool = False, loss_code: Optional[int] = None):
+    """FastRNNTOpBase::Compute on raw tensors (no autograd).  Returns (ans, px_grad|None, py_grad|None[, check]).
+    ``loss_code`` (0 none / 1 mean / 2 sum, with ``ans_grad_is_one`` and ``need_grads``): the backward launch also writes the
+    negated / reduced loss (ftr_mutual_information_bwd_loss_ws_f32) and it is returned as a fourth element."""
     _require_gpu(px, "px"); _require_gpu(py, "py")
     if px.dtype != torch.float32 or py.dtype != torch.float32:
         raise TypeError("px and py must be float32 (op registration: tf_fast_rnnt_op.cc:27-34)")
@@ -158,6 +160,11 @@ def mi_forward_backward(px: torch.Tensor, py: torch.Tensor, boundary: Optional[t
         else:
             ag = torch.ones((B,), dtype=torch.float32, device=px.device) if ans_grad is None else ans_grad.to(torch.float32).contiguous().clone()
             overwrite = 1
+        if loss_code is not None and ans_grad_is_one and not return_ans_grad_check:
+            loss = torch.empty((B,) if loss_code == 0 else (), dtype=torch.float32, device=px.device)
+            _lib.call("ftr_mutual_information_bwd_loss_ws_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), ws_floats, flags,
+                      _ptr(px_grad), _ptr(py_grad), _ptr(ans), int(loss_code), _ptr(loss), B, S, T, modified, st)
+            return ans, px_grad, py_grad, loss
         # p_grad = NULL: the reference's [B,S+1,T+1] gradient lattice (tf_fast_rnnt_op.cc:90-91) never exists here
         _lib.call("ftr_mutual_information_bwd_ws_f32", _ptr(px), _ptr(py), _ptr(boundary), _ptr(ws), ws_floats, flags,
                                                        None, _ptr(px_grad), _ptr(py_grad), _ptr(ag), overwrite,

@@ -213,9 +213,12 @@ class _SimpleLoss(torch.autograd.Function):
                                    delay_penalty, px, py, B, T, S, C, modified, st)
         # the recursion backward (occupancies) only when somebody wants them: the caller (calc_gradients) or autograd
         need = bool(want_occupancies) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
+        if need:      # the loss tail rides along with the recursion's backward launch
+            ans, px_grad, py_grad, loss = mi_forward_backward(px, py, boundary, True, ans_grad_is_one=True, loss_code=code)
+        else:
+            ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, False, ans_grad_is_one=True)
+            loss = _negated_reduce_native(ans, code)
         del px, py
-        loss = _negated_reduce_native(ans, code)
         if need:
             ctx.save_for_backward(am_probs, lm_probs, prod, symbols, boundary if boundary is not None else torch.empty(0),
                                   px_grad, py_grad)
@@ -947,8 +950,11 @@ class _SmoothedLoss(torch.autograd.Function):
         px, py, saved, meta = _smoothed_forward(lm, am, symbols, termination_symbol, boundary, modified, lm_only_scale,
                                                 am_only_scale, process_group, delay_penalty)
         need = bool(want_occupancies) or ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, need, ans_grad_is_one=True)
-        loss = _negated_reduce_native(ans, code)
+        if need:      # the loss tail rides along with the recursion's backward launch
+            ans, px_grad, py_grad, loss = mi_forward_backward(px, py, boundary, True, ans_grad_is_one=True, loss_code=code)
+        else:
+            ans, px_grad, py_grad = mi_forward_backward(px, py, boundary, False, ans_grad_is_one=True)
+            loss = _negated_reduce_native(ans, code)
         if need:
             ctx.save_for_backward(*saved, px_grad, py_grad)
         else:
