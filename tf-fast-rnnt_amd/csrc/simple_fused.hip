@@ -63,10 +63,17 @@ __global__ __launch_bounds__(256, 2) void simple_fused_fwd_kernel(
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   {
     const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-    if ((total & 31u) == 0 && (size_t)16 * NS * C * sizeof(float) <= 512 * 1024) {
+    const size_t rowset = (size_t)16 * NS * C * sizeof(float);
+    if ((total & 31u) == 0 && rowset <= 512 * 1024) {
       const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
       const unsigned per = total >> 3, slot = lin >> 3;
       const unsigned j = (lin & 7u) * per + (slot & 3u) * (per >> 2) + (slot >> 2);
+      bx = j % gridDim.x; by = (j / gridDim.x) % gridDim.y; bz = j / (gridDim.x * gridDim.y);
+    }
+    else if ((total & 15u) == 0 && rowset <= 1024 * 1024) {   // larger row sets (c4 with 128-frame tiles: 655 KB): two streams, 484 -> 476 us
+      const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const unsigned per = total >> 3, slot = lin >> 3;
+      const unsigned j = (lin & 7u) * per + (slot & 1u) * (per >> 1) + (slot >> 1);
       bx = j % gridDim.x; by = (j / gridDim.x) % gridDim.y; bz = j / (gridDim.x * gridDim.y);
     }
   }
