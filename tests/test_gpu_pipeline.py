@@ -892,3 +892,22 @@ def test_gemm_kernel_selection(ft, dev, monkeypatch):
     ft.tune_normalizer_gemms(True, when="first")
     assert os.environ["FTR_GEMM_TUNE"] == "first"
     monkeypatch.delenv("FTR_GEMM_TUNE")
+
+
+@pytest.mark.parametrize("shape", [(3, 40, 12, 20), (2, 65, 0, 7), (1, 1, 5, 516)])
+def test_rowmax_exp_pair_is_the_two_single_launches(ft, dev, shape):
+    """ftr_rowmax_exp_pair_f32 (am and lm of the simple builder in one launch) against two ftr_rowmax_exp_f32 calls: same bits."""
+    B, T, S, C = shape
+    g = torch.Generator(device="cpu").manual_seed(C)
+    am = (3.0 * torch.randn((B * T, C), generator=g)).to(dev); lm = (3.0 * torch.randn((B * (S + 1), C), generator=g)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L = ft._lib
+    ap, lp = torch.empty_like(am), torch.empty_like(lm)
+    amx, lmx = torch.empty(B * T, device=dev), torch.empty(B * (S + 1), device=dev)
+    L.call("ftr_rowmax_exp_f32", am.data_ptr(), ap.data_ptr(), amx.data_ptr(), B * T, C, st)
+    L.call("ftr_rowmax_exp_f32", lm.data_ptr(), lp.data_ptr(), lmx.data_ptr(), B * (S + 1), C, st)
+    ap2, lp2 = torch.full_like(am, float("nan")), torch.full_like(lm, float("nan"))
+    amx2, lmx2 = torch.full_like(amx, float("nan")), torch.full_like(lmx, float("nan"))
+    L.call("ftr_rowmax_exp_pair_f32", am.data_ptr(), ap2.data_ptr(), amx2.data_ptr(), B * T, lm.data_ptr(), lp2.data_ptr(), lmx2.data_ptr(),
+           B * (S + 1), C, st)
+    assert torch.equal(ap, ap2) and torch.equal(lp, lp2) and torch.equal(amx, amx2) and torch.equal(lmx, lmx2)
