@@ -10,6 +10,8 @@
 // All integer results are bit-exact with oracle/mi_oracle.c; the float window sums use the same
 // canonical order (sequential f32 cumsum along S, additions only -> no contraction possible).
 #include "ftr_common.h"
+#include <cstring>
+#include <cstdlib>
 #include <limits.h>
 
 namespace ftr {
@@ -102,6 +104,77 @@ __global__ void prune_argmax_kernel(const float* __restrict__ px_grad, const flo
   int pad = se - r + 1;                                                  // :744-746
   if (pad < 0) pad = 0;
   s_begin[(size_t)b * T + t] = (t < te - 1) ? best : pad;                // :741-748
+}
+
+// The same walk with its LOADS spread over the waves of a workgroup.  The cumulative sums have to be taken in the canonical
+// sequential order (bit-exact ranges), but the loads do not depend on them, and a column walk of S rows is 3 S loads of 256
+// bytes (64 columns) at rows 4 KB apart: one wave that takes them 64 rows at a time pays a memory round trip per 64 rows
+// (c3: 4 rounds of ~8 us, c5: 16).  Here chunk c of kSplitQ windows belongs to wave c mod NW: every wave requests its first
+// chunk at once, then the chunks are consumed in order -- the owner continues the running sums (lead, lag, best) from LDS
+// where the previous owner left them, the same additions in the same order, and requests its next chunk -- with a barrier
+// between chunks.  One round trip for up to 64 NW rows.
+constexpr int kSplitQ = 64;
+__global__ __launch_bounds__(512) void prune_argmax_split_kernel(const float* __restrict__ px_grad, const float* __restrict__ py_grad,
+                                                                 const int32_t* __restrict__ boundary, int32_t* __restrict__ s_begin,
+                                                                 int B, int S, int T, int T1, int r) {
+  __shared__ float st_lead[64], st_lag[64], st_bestv[64];
+  __shared__ int st_best[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const int b = blockIdx.y;
+  const bool live = t < T;
+  const int tc = live ? t : T - 1;                 // clamped: every lane loads, dead lanes store nothing
+  const int S1 = S + 1;
+  const int nwin = S1 - r + 1;
+  const float* pyc = py_grad + (size_t)b * S1 * T + tc;
+  const float* pxc = px_grad + (size_t)b * S * T1 + tc;
+  constexpr int Q = kSplitQ;
+  const int NC = (nwin + Q - 1) / Q;
+  float n[Q], g[Q], x[Q];
+  auto fetch = [&](int c) {
+    const int c0 = c * Q;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+      const int s0 = c0 + u;
+      const bool more = s0 + 1 < nwin;
+      n[u] = more ? pyc[(size_t)(s0 + r) * T] : 0.0f;
+      g[u] = more ? pyc[(size_t)s0 * T] : 0.0f;
+      x[u] = (s0 > 0 && s0 < nwin) ? pxc[(size_t)(s0 - 1) * T1] : 0.0f;
+    }
+  };
+  if (wave < NC) fetch(wave);
+  float lead = 0.0f, lag = 0.0f, bestv = 0.0f;
+  int best = 0;
+  if (wave == 0)
+    for (int s = 0; s < r; ++s) lead = lead + pyc[(size_t)s * T];
+  for (int c = 0; c < NC; ++c) {
+    if (c % NW == wave) {
+      if (c > 0) { lead = st_lead[lane]; lag = st_lag[lane]; bestv = st_bestv[lane]; best = st_best[lane]; }
+      const int c0 = c * Q;
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const int s0 = c0 + u;
+        if (s0 < nwin) {
+          const float blk = lead - lag;                                      // rnnt_loss.py:725
+          const float fin = blk - x[u];                                      // :726-728 (px_pad[.,0] = 0)
+          if (s0 == 0 || fin > bestv) { best = s0; bestv = fin; }            // :729, first maximum
+          if (s0 + 1 < nwin) {
+            lead = lead + n[u];
+            lag = lag + g[u];
+          }
+        }
+      }
+      if (c + 1 < NC) { st_lead[lane] = lead; st_lag[lane] = lag; st_bestv[lane] = bestv; st_best[lane] = best; }
+      if (c + NW < NC) fetch(c + NW);
+      if (c + 1 == NC && live) {
+        const int se = boundary[4 * b + 2], te = boundary[4 * b + 3];
+        int pad = se - r + 1;                                                // :744-746
+        if (pad < 0) pad = 0;
+        s_begin[(size_t)b * T + t] = (t < te - 1) ? best : pad;              // :741-748
+      }
+    }
+    if (c + 1 < NC) __syncthreads();
+  }
 }
 
 #ifndef FTR_PRUNE_CHK
@@ -772,6 +845,16 @@ int prune_ranges(const float* px_grad, const float* py_grad, const int32_t* boun
   const int threads = 64;  // small blocks: B*T threads is only ~32k at the headline shape, spread them
   const dim3 grid((T + threads - 1) / threads, B);
 #define FTR_ARGMAX_ONCE(R) case R: hipLaunchKernelGGL(prune_argmax_once_kernel<R>, grid, dim3(threads), 0, st, px_grad, py_grad, boundary, s_begin, B, S, T, T1); break;
+  const int nwin = S + 1 - r + 1;
+  static const bool split_off = getenv("FTR_PRUNE_ARGMAX_SPLIT") && !strcmp(getenv("FTR_PRUNE_ARGMAX_SPLIT"), "0");   // A/B knob
+  // ... where one wave per 64 columns leaves the chip short of waves (c3: 512 of them on 256 CUs, 41.5 -> 34 us); with a
+  // thousand and more the one-wave kernel already keeps 8 waves per CU loading and the split only costs (c4 67 -> 109 us,
+  // c5 191 -> 436)
+  if (nwin > ftr::kSplitQ && (size_t)((T + 63) / 64) * B <= 768 && !split_off) {
+    const int nc = (nwin + ftr::kSplitQ - 1) / ftr::kSplitQ;
+    const int nw = nc < 8 ? nc : 8;
+    hipLaunchKernelGGL(prune_argmax_split_kernel, dim3((T + 63) / 64, B), dim3(64 * nw), 0, st, px_grad, py_grad, boundary, s_begin, B, S, T, T1, r);
+  } else
   switch (r) {   // window lengths up to 16: py_grad is loaded once; longer windows: the generic kernel
     FTR_ARGMAX_ONCE(1) FTR_ARGMAX_ONCE(2) FTR_ARGMAX_ONCE(3) FTR_ARGMAX_ONCE(4) FTR_ARGMAX_ONCE(5) FTR_ARGMAX_ONCE(6)
     FTR_ARGMAX_ONCE(7) FTR_ARGMAX_ONCE(8) FTR_ARGMAX_ONCE(9) FTR_ARGMAX_ONCE(10) FTR_ARGMAX_ONCE(11) FTR_ARGMAX_ONCE(12)
