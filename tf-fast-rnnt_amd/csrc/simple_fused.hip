@@ -593,7 +593,14 @@ int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, c
   const int blocks = (S + 1 + 15) / 16;
   const int ny = (blocks + 12) / 13;
   const int need = (blocks + ny - 1) / ny;                     // symbol blocks per workgroup, <= 13
-  const int ns = need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : 13;
+  int ns = need <= 4 ? 4 : need <= 7 ? 7 : need <= 10 ? 10 : 13;
+  // a small problem in large tiles leaves CUs with one workgroup or none (c2: 288 workgroups of 112 rows on 256 CUs, one
+  // wave per SIMD): smaller symbol tiles until there are two per CU (c2 51 -> 44 us; B = 8, T = 1000, S = 200: 51 -> 34)
+  {
+    const size_t ftiles = (size_t)((T1 + 63) / 64) * B;
+    while (ns > 4 && ftiles * ((blocks + ns - 1) / ns) < 512) ns -= 3;
+  }
+  if (const char* e = getenv("FTR_FUSED_NS")) { const int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13) ns = v; }   // A/B measurements
   // 128-frame tiles where one utterance's lm_probs rows of a tile (16 ns C floats) exceed what the XCD-aware order keeps in
   // an L2 (> 512 KB: that order is off, every frame tile fetches the rows through the fabric) and there are frames for it;
   // FTR_FUSED_FT = 64 | 128 forces one (A/B measurements)
