@@ -696,16 +696,20 @@ def test_against_committed_golden_fixtures(ft, dev, name):
         close(logits.grad, f"pruned_logits_grad_r{r}")
 
 
+@pytest.mark.parametrize("blocks", ["4", "7", "10", "13"])
 @pytest.mark.parametrize("frames", ["64", "128"])
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
 @pytest.mark.parametrize("cfg", [(2, 70, 33, 12), (2, 129, 100, 20), (1, 200, 140, 16), (2, 65, 200, 8), (1, 63, 470, 24), (3, 64, 15, 36),
                                  (2, 1, 0, 4), (2, 5, 0, 8), (1, 3, 70, 4), (2, 64, 1, 4), (1, 300, 40, 72)])
-def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cfg, frames, monkeypatch):
-    """csrc/simple_fused.hip (f32-MFMA contraction + epilogue in one kernel) against the library-GEMM + epilogue route on
-    shapes that hit every symbol-block count (4 / 7 / 10 / 13 per workgroup), several symbol tiles, ragged frame tiles,
-    boundaries and the penalty; simple and smoothed; with 64- and with 128-frame tiles (the launcher takes the latter only for
-    large lm_probs row sets: forced here).  Same -inf pattern, values to 2e-5 (summation order differs)."""
+def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cfg, frames, blocks, monkeypatch):
+    """csrc/simple_fused.hip (f32-MFMA contraction + epilogue in one kernel) against the library-GEMM + epilogue route with
+    every symbol-block count (4 / 7 / 10 / 13 per workgroup: the launcher would take 4 for problems this small, so the count
+    is forced), one and several symbol tiles (with several, the tile order that puts a frame block's symbol tiles side by
+    side), ragged frame tiles, boundaries and the penalty; simple and smoothed; with 64- and with 128-frame tiles (the launcher
+    takes the latter only for large lm_probs row sets: forced here).  Same -inf pattern, values to 2e-5 (summation order
+    differs)."""
     monkeypatch.setenv("FTR_FUSED_FT", frames)
+    monkeypatch.setenv("FTR_FUSED_NS", blocks)
     B, T, S, C = cfg
     d = synthetic(11 + S, B, T, S, C, ragged=True)
     lm, am, sym, bnd = (_t(d[k], dev) for k in ("lm", "am", "symbols", "boundary"))

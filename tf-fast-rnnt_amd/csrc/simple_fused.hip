@@ -600,7 +600,7 @@ int simple_fused_fwd(const float* am, const float* lm, const int32_t* symbols, c
     const size_t ftiles = (size_t)((T1 + 63) / 64) * B;
     while (ns > 4 && ftiles * ((blocks + ns - 1) / ns) < 512) ns -= 3;
   }
-  if (const char* e = getenv("FTR_FUSED_NS")) { const int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13) ns = v; }   // A/B measurements
+  if (const char* e = getenv("FTR_FUSED_NS")) { const int v = atoi(e); if (v == 4 || v == 7 || v == 10 || v == 13) ns = v; }   // A/B measurements, tests
   // 128-frame tiles where one utterance's lm_probs rows of a tile (16 ns C floats) exceed what the XCD-aware order keeps in
   // an L2 (> 512 KB: that order is off, every frame tile fetches the rows through the fabric) and there are frames for it;
   // FTR_FUSED_FT = 64 | 128 forces one (A/B measurements)
