@@ -478,8 +478,12 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
     park(0, g);
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
+#if !(defined(FTR_FUSED_BWD_EXP) && FTR_FUSED_BWD_EXP == 3)   // study build 3: no loads in the loop (the first chunk's operands again)
       if (kc + 1 < nk) load(kc + 1, g, true);
+#endif
+#if !(defined(FTR_FUSED_BWD_EXP) && FTR_FUSED_BWD_EXP == 2)   // study build 2: no MFMAs in pass 1
       compute(kc);
+#endif
       if (kc + 1 < nk) park(kc + 1, g);
       __syncthreads();
     }
@@ -526,7 +530,11 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
     float* xT = lmT;                               // [kB2][kBT]
     int* sym2 = reinterpret_cast<int*>(wT);        // [kB2]
     constexpr int NX = kB2 * (kBT / 4) / 256;      // 8 quads per thread and stage
+#if defined(FTR_FUSED_BWD_EXP) && FTR_FUSED_BWD_EXP == 1       // study build 1: no pass 2
+    for (int r0 = 0; r0 < 0; r0 += kB2) {
+#else
     for (int r0 = 0; r0 < S; r0 += kB2) {
+#endif
       f4 xv[NX];
 #pragma unroll
       for (int u = 0; u < NX; ++u) {
