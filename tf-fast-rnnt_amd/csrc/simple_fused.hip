@@ -529,29 +529,58 @@ __global__ __launch_bounds__(256, 2) void simple_fused_bwd_am_kernel(
     static_assert(kB2 * kBT <= 2 * kBS * LDC && kB2 <= 2 * kBS * kBLT, "pass 2 reuses the tiles of pass 1");
     float* xT = lmT;                               // [kB2][kBT]
     int* sym2 = reinterpret_cast<int*>(wT);        // [kB2]
+    // Only the rows whose symbol falls into this workgroup's CT columns contribute -- one row in C / CT -- so they are
+    // listed first (ascending, ballot compaction over 256 rows at a time) and only those are fetched and walked: at c4
+    // (four column groups) this pass was 114 of the kernel's 648 us with every group walking all S rows.
+    constexpr int kCap = (2 * kBS * kBLT - kB2) * 2;                                 // list capacity (16-bit entries behind sym2)
+    unsigned short* rlist = reinterpret_cast<unsigned short*>(wT + kB2);
+    int* wcnt = reinterpret_cast<int*>(csb);                                         // [4]; the column sums have been read
+    int count = 0;
+    const bool listed = S <= 65535;
+    __syncthreads();                               // pass 1 and the column sums are done with wT / csb
+    if (listed) {
+      for (int base = 0; base < S; base += 256) {
+        const int srow = base + tid;
+        const int sy = srow < S ? min(max(symbols[(size_t)b * S + srow], 0), C - 1) : -1;
+        const bool mine = sy >= c0 && sy < c0 + CT;
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = count;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        const int at = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (mine && at < kCap) rlist[at] = (unsigned short)srow;
+        count += tot;
+        __syncthreads();
+      }
+    }
+    const bool all_rows = !listed || count > kCap;  // (more listed rows than the list holds: every row, as before)
+    if (all_rows) count = S;
+    auto row_of = [&](int i) { return all_rows ? i : (int)rlist[i]; };
     constexpr int NX = kB2 * (kBT / 4) / 256;      // 8 quads per thread and stage
 #if defined(FTR_FUSED_BWD_EXP) && FTR_FUSED_BWD_EXP == 1       // study build 1: no pass 2
     for (int r0 = 0; r0 < 0; r0 += kB2) {
 #else
-    for (int r0 = 0; r0 < S; r0 += kB2) {
+    for (int r0 = 0; r0 < count; r0 += kB2) {
 #endif
       f4 xv[NX];
 #pragma unroll
       for (int u = 0; u < NX; ++u) {
-        const int row = r0 + wrow + 16 * u;
-        xv[u] = *reinterpret_cast<const f4u*>(gxb + (size_t)min(row, S - 1) * T1 + wtc);
+        const int row = row_of(min(r0 + wrow + 16 * u, count - 1));
+        xv[u] = *reinterpret_cast<const f4u*>(gxb + (size_t)row * T1 + wtc);
       }
-      const int srow = r0 + tid;
-      const int symr = (tid < kB2 && srow < S) ? min(max(symbols[(size_t)b * S + min(srow, S - 1)], 0), C - 1) : -1;
-      __syncthreads();                             // the previous stage (or pass 1 / the column sums) is done with the area
+      const int li = r0 + tid;
+      const int symr = (tid < kB2 && li < count) ? min(max(symbols[(size_t)b * S + row_of(li)], 0), C - 1) : -1;
+      __syncthreads();                             // the previous stage is done with the area
 #pragma unroll
       for (int u = 0; u < NX; ++u) {
-        const float rowx = (r0 + wrow + 16 * u < S) ? kdir : 0.0f;
+        const float rowx = (r0 + wrow + 16 * u < count) ? kdir : 0.0f;
         *reinterpret_cast<f4*>(xT + (wrow + 16 * u) * kBT + 4 * wq) = xv[u] * xmask * rowx;
       }
       if (tid < kB2) sym2[tid] = symr;
       __syncthreads();
-      const int nks = (min(kB2, S - r0) + 3) / 4;
+      const int nks = (min(kB2, count - r0) + 3) / 4;
       for (int kk = 0; kk < nks; ++kk) {
         const float bx = xT[(4 * kk + fk) * kBT + 16 * wave + fn];
         // this lane's A element (k row 4 kk + fk, block row fn) is 1 in block 4 g + e iff the row's symbol is local
