@@ -734,11 +734,14 @@ def test_fused_builder_matches_library_gemm_route(ft, dev, oracle, rnnt_type, cf
 
 @pytest.mark.parametrize("rnnt_type", ["regular", "modified"])
 @pytest.mark.parametrize("cfg", [(2, 72, 33, 12), (2, 129, 100, 20), (1, 200, 140, 260), (2, 68, 200, 8), (3, 64, 15, 36), (2, 100, 7, 600), (1, 76, 330, 16),
-                                 (2, 132, 61, 1024), (2, 4, 3, 4), (1, 60, 0, 8)])
+                                 (2, 132, 61, 1024), (2, 4, 3, 4), (1, 60, 0, 8), (1, 12, 700, 520), (1, 8, 4300, 12)])
 def test_fused_d_am_kernel_matches_library_gemm_route(ft, dev, rnnt_type, cfg, monkeypatch):
     """The fused backward towards am (the default: W^T lm_probs as MFMA inside the kernel, scatter by symbol as a one-hot
     MFMA contraction) against the library route (FTR_BUILDER_BWD=library: library GEMM + epilogue kernel): gradients of the
-    simple and of the smoothed loss w.r.t. am and lm, with boundaries and a non-uniform upstream gradient."""
+    simple and of the smoothed loss w.r.t. am and lm, with boundaries and a non-uniform upstream gradient.  The scatter pass
+    walks a per-workgroup list of the rows whose symbol lies in its 256 columns: the cases cover one and several column groups,
+    lists built in several 256-row batches (S = 330, 700) and more listed rows than the list holds (S = 4300 in one column
+    group: every row is walked, as before the list)."""
     B, T, S, C = cfg
     d = synthetic(23 + S, B, T, S, C, ragged=True)
     sym, bnd = _t(d["symbols"], dev), _t(d["boundary"], dev)
