@@ -22,6 +22,26 @@ inline int check_launch(const char* what) {
   return FTR_OK;
 }
 
+// Zero fill / device copy of 32-bit words as KERNELS.  Not hipMemsetAsync / hipMemcpyAsync: a memset node captured into a
+// hipGraph writes the right value on the first replay only on this ROCm (scripts/graph_memset_probe.py: garbage from the
+// second replay on), and every launch of this library must be capturable -- the recursion's hand-off region is cleared by
+// such a node whenever the caller does not vouch for a clean workspace.
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n);
+__global__ void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n);
+inline int zero_words(void* p, size_t n_words, hipStream_t st, const char* what) {
+  if (n_words == 0) return FTR_OK;
+  const size_t blocks = (n_words + 4 * 256 - 1) / (4 * 256);
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, static_cast<uint32_t*>(p), n_words);
+  return check_launch(what);
+}
+inline int copy_words(void* dst, const void* src, size_t n_words, hipStream_t st, const char* what) {
+  if (n_words == 0) return FTR_OK;
+  const size_t blocks = (n_words + 255) / 256;
+  hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, static_cast<uint32_t*>(dst),
+                     static_cast<const uint32_t*>(src), n_words);
+  return check_launch(what);
+}
+
 // A "minus infinity" that stays finite under the additions of the recursion, so the dependent chain
 // needs no NaN guard: anything <= NEG_THRESH is reported as -inf when it leaves a kernel.
 constexpr float kNeg = -1.0e30f;

@@ -805,7 +805,8 @@ size_t mi_band_workspace_floats(int B, int T, int S, int r) {
 }
 
 int band_ranges_check(const int32_t* ranges, const int32_t* boundary, int* flags, int B, int T, int r, hipStream_t st) {
-  if (hipMemsetAsync(flags, 0, sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); set_error("band_ranges_check: memset failed"); return FTR_ERR_LAUNCH; }
+  const int rcz = zero_words(flags, 1, st, "band_ranges_check");
+  if (rcz != FTR_OK) return rcz;
   const size_t n = (size_t)B * T;
   if (n == 0) return FTR_OK;
   hipLaunchKernelGGL(band_ranges_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ranges, boundary, flags, B, T, r);

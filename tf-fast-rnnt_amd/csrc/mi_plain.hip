@@ -159,10 +159,8 @@ int mi_plain_bwd(const float* px, const float* py, const int32_t* boundary, cons
   if (lds > 64 * 1024) { set_error("mi_plain_bwd: S=%d too large for the plain family", S); return FTR_ERR_UNSUPPORTED; }
   const int T1 = modified ? T : T + 1;
   // the reference zero-fills both outputs before the kernel (tf_fast_rnnt_op.cc:93-96)
-  if (hipMemsetAsync(px_grad, 0, sizeof(float) * (size_t)B * S * T1, st) != hipSuccess ||
-      hipMemsetAsync(py_grad, 0, sizeof(float) * (size_t)B * (S + 1) * T, st) != hipSuccess) {
-    set_error("mi_plain_bwd: memset failed"); return FTR_ERR_LAUNCH;
-  }
+  if (zero_words(px_grad, (size_t)B * S * T1, st, "mi_plain_bwd") != FTR_OK ||
+      zero_words(py_grad, (size_t)B * (S + 1) * T, st, "mi_plain_bwd") != FTR_OK) return FTR_ERR_LAUNCH;
   const int threads = 256;
   if (modified) hipLaunchKernelGGL(mi_plain_bwd_kernel<true>, dim3(B), dim3(threads), lds, st, px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite, S, T);
   else hipLaunchKernelGGL(mi_plain_bwd_kernel<false>, dim3(B), dim3(threads), lds, st, px, py, boundary, p, p_grad, px_grad, py_grad, ans_grad, overwrite, S, T);

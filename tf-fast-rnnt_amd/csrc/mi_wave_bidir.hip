@@ -43,6 +43,23 @@
 
 namespace ftr {
 using namespace wavecfg;
+
+// (declared in ftr_common.h: the library's replacement for memset / memcpy nodes)
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const size_t n4 = n >> 2;
+    for (size_t i = i0; i < n4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = 4 * n4 + i0; i < n; i += stride) p[i] = 0u;
+  } else {
+    for (size_t i = i0; i < n; i += stride) p[i] = 0u;
+  }
+}
+__global__ void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 namespace {
 
 // Prefetch depth of the IO-in wave (chunks in flight in registers) and the back-off of a COMM wave whose granules are
@@ -1568,10 +1585,7 @@ int check_ws(const char* what, const float* ws, size_t ws_floats, const BidirLay
 }
 // zeroes the hand-off region (ctrl + both granule regions)
 int clear_handoff(const char* what, float* ws, const BidirLayout& l, hipStream_t st) {
-  if (hipMemsetAsync(ws + l.ctrl_off, 0, sizeof(float) * (l.total - l.ctrl_off), st) != hipSuccess) {
-    (void)hipGetLastError(); set_error("%s: memset of the hand-off region failed", what); return FTR_ERR_LAUNCH;
-  }
-  return FTR_OK;
+  return zero_words(ws + l.ctrl_off, l.total - l.ctrl_off, st, what);   // a kernel, not a memset node: see ftr_common.h
 }
 }  // namespace
 
@@ -1645,9 +1659,8 @@ int mi_bidir_bwd(const int32_t* boundary, const float* ws, size_t ws_floats, int
   const float* seed = ans_grad;
   float* check = nullptr;
   if (ans_grad && overwrite) {
-    if (hipMemcpyAsync(wsm + l.seed_off, ans_grad, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-      (void)hipGetLastError(); set_error("mi_bidir_bwd: seed snapshot failed"); return FTR_ERR_LAUNCH;
-    }
+    rc = copy_words(wsm + l.seed_off, ans_grad, (size_t)B, st, "mi_bidir_bwd: seed snapshot");
+    if (rc != FTR_OK) return rc;
     seed = wsm + l.seed_off;
     check = ans_grad;
   }
