@@ -58,3 +58,21 @@ def test_step_replays_from_a_graph_with_new_values(ft, dev, kind):
         torch.cuda.synchronize()
         for k, v in got.items():
             _same(v, ref[k], f"{kind} seed {seed}: {k}")
+
+
+@pytest.mark.parametrize("kind", ["simple", "pruned", "pruned_smoothed"])
+def test_step_is_bit_reproducible(ft, dev, kind):
+    """The same step on the same inputs twice: every output bit for bit (no atomics in any reduction of the path, a fixed
+    order in every scatter; the library GEMMs keep the kernel they have chosen by then)."""
+    B, T, S, C, r = 3, 136, 40, 36, 5
+    inp = bench.make_inputs(B, T, S, C, 9, dev, ragged=True)
+    if kind == "simple":
+        step = lambda: bench.simple_step(inp, keep=True)
+    else:
+        step = lambda: bench.pruned_step(inp, r, keep=True, first_pass="smoothed" if kind == "pruned_smoothed" else "simple")
+    for _ in range(3):
+        step()
+    a = {k: v.detach().cpu().numpy().copy() for k, v in step().items() if v is not None}
+    b = {k: v.detach().cpu().numpy().copy() for k, v in step().items() if v is not None}
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), f"{kind}: {k} differs between two runs"
