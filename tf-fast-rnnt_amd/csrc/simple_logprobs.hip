@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void simple_bwd_w_kernel(const float* __restri
 #define FTR_BWD_AM_PF 1     // frames whose write-out operands are fetched at the top of the kernel.  Measured (scripts/bwd_am_ab.sh,
                             // c3 / c2 / c5 / c4 in us): 1 -> 53 / 23.6 / 370 / 281, 4 -> 54.7 / 24.2 / 369 / 277, 6 -> 58.7 / 26.5 / 383 / 290,
                             // 8 at three workgroups per CU -> 63 / 34.5 / 370 / 281 (170 registers), 2 -> 57 / 25.5 / 488 / 306 (!);
+                            // 0 -> 51.5 / 24.0 / 402 / 284 (one frame's operands are what gives the write-out its head start);
                             // the previous revision (no prefetch, four loads in flight in the sweeps): 54 / 23.0 / 431 / 299.
 #endif
 #ifndef FTR_BWD_AM_WGS
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256, FTR_BWD_AM_WGS) void simple_bwd_am_kernel(cons
   // four workgroups per CU do not already hide, and costs occupancy beyond a frame or two (see FTR_BWD_AM_PF).
   constexpr int NF = TT / 2, PF = NF < FTR_BWD_AM_PF ? NF : FTR_BWD_AM_PF;   // write-out: frames per thread, of which prefetched
   const int wo_half = threadIdx.x >> 7, wo_cl = threadIdx.x & 127;
-  f4 pdp[PF], pap[PF];
+  f4 pdp[PF > 0 ? PF : 1], pap[PF > 0 ? PF : 1];   // (PF = 0: no prefetch, the arrays are unused)
   if ((C & 3) == 0) {
     const int c4 = min(wo_cl, (C >> 2) - 1);
 #pragma unroll
