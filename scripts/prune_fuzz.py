@@ -13,7 +13,7 @@ def main(n=100, seed=0):
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
     for it in range(n):
-        B = int(rng.integers(1, 4)); S = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 70])); T = int(rng.choice([1, 2, 5, 63, 64, 65, 130, 200]))
+        B = int(rng.integers(1, 4)); S = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 70, 130, 200, 331])); T = int(rng.choice([1, 2, 5, 63, 64, 65, 130, 200]))
         mod = bool(rng.integers(0, 2))
         if mod and S > T: S = T
         T1 = T if mod else T + 1
