@@ -38,9 +38,10 @@ def _same(a, b, name):
             assert np.abs(a[fin] - b[fin]).max() <= 1e-6 * max(1.0, np.abs(b[fin]).max()), name
 
 
-@pytest.mark.parametrize("kind", ["simple", "pruned", "pruned_smoothed"])
-def test_step_replays_from_a_graph_with_new_values(ft, dev, kind):
-    B, T, S, C, r = 3, 72, 20, 24, 5
+@pytest.mark.parametrize("shape", [(3, 72, 20, 24, 5), (2, 900, 250, 16, 5)])   # the second: bands of the recursion chained over
+@pytest.mark.parametrize("kind", ["simple", "pruned", "pruned_smoothed"])       # four workgroups, the band route in segments,
+def test_step_replays_from_a_graph_with_new_values(ft, dev, kind, shape):       # the split column walk of prune_ranges
+    B, T, S, C, r = shape
     inp = bench.make_inputs(B, T, S, C, 5, dev, ragged=True)
     if kind == "simple":
         step = lambda: bench.simple_step(inp, keep=True)
